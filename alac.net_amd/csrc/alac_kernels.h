@@ -1,0 +1,50 @@
+// alac_kernels.h -- launch parameters shared by the kernels and the C-ABI host code.
+#ifndef ALAC_KERNELS_H
+#define ALAC_KERNELS_H
+#include <stdint.h>
+
+// Same layout as alacgpu_cfg (include/alacgpu.h); kept separate so the kernels do not depend on the public header.
+struct alacgpu_cfg_dev {
+    uint32_t max_samples_per_frame;
+    uint8_t sample_size, rice_history_mult, rice_initial_history, rice_kmodifier;
+    uint8_t num_channels, ctor_sample_size, reserved, pad;
+};
+static_assert(sizeof(alacgpu_cfg_dev) == 12, "cfg layout");
+
+// Same numbering as ALACGPU_ST_* (include/alacgpu.h)
+enum {
+    ALACGPU_ST_OK_D = 0,
+    ALACGPU_ST_UNSUPPORTED_ELEMENT_D = 1,
+    ALACGPU_ST_UNSUPPORTED_SAMPLE_SIZE_D = 2,
+    ALACGPU_ST_UNSUPPORTED_PREDTYPE_D = 3,
+    ALACGPU_ST_BAD_SAMPLE_COUNT_D = 4,
+    ALACGPU_ST_OVERRUN_D = 5,
+    ALACGPU_ST_REF_THROWS_D = 6,
+    ALACGPU_ST_UNSUPPORTED_PARAMS_D = 7
+};
+
+struct alac_decode_params {
+    const uint8_t* blob;        // 16-byte aligned
+    uint64_t blob_limit;        // readable bytes from blob (blob_bytes rounded up to 16)
+    const uint64_t* offsets;
+    const uint32_t* sizes;
+    const uint16_t* cfg_idx;    // may be null
+    const alacgpu_cfg_dev* cfgs;
+    uint32_t n_cfgs;
+    uint32_t n_packets;
+    int32_t* pcm_out;
+    uint32_t slot_ints;
+    int32_t* out_bytes;         // may be null
+    int32_t* out_samples;       // may be null
+    int32_t* status;
+};
+
+#ifdef __HIPCC__
+extern "C" __global__ void alac_decode_packets_kernel(alac_decode_params p);
+#endif
+
+// packets decoded per workgroup by alac_decode_packets_kernel
+#define ALAC_PACKETS_PER_WG 2
+#define ALAC_WG_THREADS 64
+
+#endif

@@ -1,0 +1,129 @@
+/*
+ * alacgpu.h -- C ABI of libalacgpu.so: the MI355X (gfx950) batched ALAC frame-decode path.
+ *
+ * This is the drop-in boundary for teekay/ALAC.NET's per-packet decode seam.  The reference has
+ * no FFI; the seam is the managed call
+ *     AlacContext.cs:54-55   _alac = new AlacFile(SampleSize, NumChannels); _alac.SetInfo(CodecData);
+ *     AlacContext.cs:197     var outputBytes = _alac.DecodeFrame(_readBuffer, pDestBuffer);
+ * and each entry point below names the reference member it replaces.  A C# host binds these with
+ * [DllImport("alacgpu")].  Plain pointers and sizes only; caller allocates
+ * everything; the library never keeps a caller pointer past the call; one ctx per host thread.
+ *
+ * Return codes: 0 = the batch ran (inspect status[]), < 0 = batch-level failure.
+ * There is NO CPU fallback: if no gfx950 device / kernel image is usable, create fails.
+ */
+#ifndef ALACGPU_H
+#define ALACGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ALACGPU_VERSION 1
+
+/* Stream configuration = the AlacFile ctor args + what AlacFile.SetInfo keeps
+ * (AlacFile.cs:16-20 and :63-93; CodecData byte offsets in brackets). 12 bytes, blittable. */
+typedef struct {
+    uint32_t max_samples_per_frame; /* [24..27] BE32, AlacFile.cs:72  */
+    uint8_t  sample_size;           /* [29]            AlacFile.cs:76  (16 or 24 decode; others -> status) */
+    uint8_t  rice_history_mult;     /* [30]            AlacFile.cs:78  */
+    uint8_t  rice_initial_history;  /* [31]            AlacFile.cs:80  */
+    uint8_t  rice_kmodifier;        /* [32]            AlacFile.cs:82  (1..16 supported) */
+    uint8_t  num_channels;          /* ctor arg,       AlacFile.cs:18  (1 or 2) */
+    uint8_t  ctor_sample_size;      /* ctor arg samplesize (AlacFile.cs:19); 0 = same as sample_size */
+    uint8_t  reserved;
+} alacgpu_cfg;
+
+/* Per-packet status[] values.  The reference signals these by exceptions / silent no-ops. */
+enum {
+    ALACGPU_ST_OK = 0,
+    ALACGPU_ST_UNSUPPORTED_ELEMENT = 1,     /* channels field not 0/1: reference decodes nothing (AlacFile.cs:437,:577) */
+    ALACGPU_ST_UNSUPPORTED_SAMPLE_SIZE = 2, /* Exception("FIXME: unimplemented sample size N") (AlacFile.cs:574,:715) */
+    ALACGPU_ST_UNSUPPORTED_PREDTYPE = 3,    /* Exception("FIXME: unhandled predicition type: N") (AlacFile.cs:650,:660) */
+    ALACGPU_ST_BAD_SAMPLE_COUNT = 4,        /* hassize count <= 0, > 16384 or > slot (IndexOutOfRangeException) */
+    ALACGPU_ST_OVERRUN = 5,                 /* bitstream ran past the packet / zero run past the scratch (AlacFile.cs:242) */
+    ALACGPU_ST_REF_THROWS = 6,              /* N == 0 && n > 4096: Array.Copy ArgumentException (AlacFile.cs:264-265) */
+    ALACGPU_ST_UNSUPPORTED_PARAMS = 7       /* header/parameter combination outside the supported domain */
+};
+
+/* Batch-level return codes */
+enum {
+    ALACGPU_OK = 0,
+    ALACGPU_ERR_BAD_ARG = -1,
+    ALACGPU_ERR_NO_DEVICE = -2,          /* no usable gfx950 GPU: there is no CPU fallback */
+    ALACGPU_ERR_HIP = -3,                /* a HIP runtime call failed; see alacgpu_last_error */
+    ALACGPU_ERR_UNSUPPORTED_CONFIG = -4, /* a cfg is outside the kernel's domain (rice_kmodifier not in 1..16, channels not 1/2) */
+    ALACGPU_ERR_NO_MEMORY = -5
+};
+
+typedef struct alacgpu_ctx alacgpu_ctx;
+
+int alacgpu_version(void);
+
+/* Replaces `new AlacFile(samplesize, numchannels)` + `SetInfo(codecData)` (AlacContext.cs:54-55)
+ * for one or more streams at once (a batch may mix streams through cfg_idx[]).
+ * device = HIP device ordinal. */
+int alacgpu_create(const alacgpu_cfg* cfgs, uint32_t n_cfgs, int device, alacgpu_ctx** out_ctx);
+
+void alacgpu_destroy(alacgpu_ctx* ctx);
+
+/* Parses the int-per-byte CodecData array exactly as AlacFile.SetInfo does (AlacFile.cs:63-93). */
+int alacgpu_cfg_from_codec_data(const int32_t* codec_data_ints, uint32_t n_ints, int samplesize, int numchannels,
+                                alacgpu_cfg* out_cfg);
+
+/*
+ * Batched AlacFile.DecodeFrame (AlacFile.cs:428-719) on HOST buffers: H2D, decode kernel, D2H; blocking.
+ *   blob/blob_bytes      concatenated raw ALAC packets
+ *   offsets[p], sizes[p] packet p = blob[offsets[p] .. offsets[p]+sizes[p])   (any byte alignment)
+ *   cfg_idx[p]           stream cfg of packet p; NULL = all 0
+ *   pcm_out              packet p decodes to pcm_out + p*slot_ints, ONE int32 PER SAMPLE interleaved by the
+ *                        stream's num_channels (16-bit: exactly the ints DecodeFrame stores; 24-bit: the
+ *                        sample sign-extended -- DecodeFrame's byte-per-int layout is alacgpu_expand_reference_layout)
+ *   slot_ints            >= max n*num_channels over the batch
+ *   out_bytes[p]         DecodeFrame's return value (AlacFile.cs:718); may be NULL
+ *   out_samples[p]       samples per channel in packet p; may be NULL
+ *   status[p]            ALACGPU_ST_*
+ */
+int alacgpu_decode_batch(alacgpu_ctx* ctx, const uint8_t* blob, uint64_t blob_bytes, const uint64_t* offsets,
+                         const uint32_t* sizes, const uint16_t* cfg_idx, uint32_t n_packets, int32_t* pcm_out,
+                         uint32_t slot_ints, int32_t* out_bytes, int32_t* out_samples, int32_t* status);
+
+/*
+ * Same, on DEVICE buffers already resident in HBM (all pointers are device pointers), asynchronous on
+ * `hip_stream` (a hipStream_t; NULL = default stream).  d_blob must be 16-byte aligned and readable up to
+ * blob_bytes rounded up to 16.  Outputs as above; d_out_bytes / d_out_samples may be NULL.
+ */
+int alacgpu_decode_batch_device(alacgpu_ctx* ctx, const void* d_blob, uint64_t blob_bytes, const void* d_offsets,
+                                const void* d_sizes, const void* d_cfg_idx, uint32_t n_packets, void* d_pcm_out,
+                                uint32_t slot_ints, void* d_out_bytes, void* d_out_samples, void* d_status,
+                                void* hip_stream);
+
+/* Single-packet drop-in for `int DecodeFrame(byte[] inbuffer, int[] outbuffer)` (AlacFile.cs:428):
+ * writes the reference's own int[] layout (24-bit: one int per byte) and returns its byte count in
+ * *out_bytes.  status as above (the C# shim rethrows the reference's exceptions from it). */
+int alacgpu_decode_frame(alacgpu_ctx* ctx, uint32_t cfg_index, const uint8_t* inbuffer, uint32_t in_bytes,
+                         int32_t* outbuffer, uint32_t out_capacity_ints, int32_t* out_bytes, int32_t* status);
+
+/* Host-side reshape: canonical int32-per-sample -> the exact int[] DecodeFrame writes
+ * (AlacFile.cs:390-395,:555-557 for 24-bit; identity for 16-bit).  Returns ints written. */
+size_t alacgpu_expand_reference_layout(const alacgpu_cfg* cfg, const int32_t* pcm, int32_t n_samples,
+                                       int32_t* ref_ints);
+
+/* AlacContext.FormatSamples (AlacContext.cs:214-256): reference int[] -> little-endian PCM bytes. */
+size_t alacgpu_format_samples(int bytes_per_sample, const int32_t* ref_ints, int32_t count_bytes, uint8_t* dst);
+
+/* Average kernel time of the last alacgpu_decode_batch* call's launch, from HIP events recorded
+ * on the launch stream (milliseconds; < 0 if unavailable).  Synchronises the stream. */
+float alacgpu_last_kernel_ms(alacgpu_ctx* ctx);
+
+const char* alacgpu_strerror(int rc);
+const char* alacgpu_status_string(int status);
+const char* alacgpu_last_error(alacgpu_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -136,6 +136,7 @@ static int entropy_rice_decode(bitrd* b, int32_t* outputBuffer, int outputSize, 
     int outputCount = 0;
     int32_t signModifier = 0;
     int st = 0;
+    int negative_history = 0;
     while (outputCount < outputSize) {
         int initialK = 31 - riceKmodifier - alac_oracle_count_leading_zeros(cs_add(cs_sar(history, 9), 3));
         int k = initialK < 0 ? initialK + riceKmodifier : riceKmodifier;
@@ -148,6 +149,9 @@ static int entropy_rice_decode(bitrd* b, int32_t* outputBuffer, int outputSize, 
                       : cs_sub(cs_add(history, cs_mul(decodedValue, riceHistorymult)),
                                cs_sar(cs_mul(history, riceHistorymult), 9));
         if (history < 128 && outputCount + 1 < outputSize) {
+            /* a negative history (only reachable through 32-bit wrap with exotic multipliers) makes the
+             * reference read a negative bit count; outside the supported domain, flagged */
+            if (history < 0) negative_history = 1;
             signModifier = 1;
             k = alac_oracle_count_leading_zeros(history) + ((history + 16) / 64) - 24;
             int32_t blockSize = entropy_decode_value(b, 16, k, riceKmodifierMask);
@@ -167,6 +171,7 @@ static int entropy_rice_decode(bitrd* b, int32_t* outputBuffer, int outputSize, 
         }
         outputCount++;
     }
+    if (!st && negative_history) st = ALAC_ORACLE_UNSUPPORTED_PARAMS;
     return st;
 }
 
