@@ -1,0 +1,383 @@
+// alac_device.h -- device-side building blocks shared by the ALAC decode kernels (gfx950 only).
+// Bit reader, adaptive Golomb-Rice step, adaptive FIR step, header parse.  Reference line numbers are
+// ALACDecoder/AlacFile.cs of teekay/ALAC.NET.
+#ifndef ALAC_DEVICE_H
+#define ALAC_DEVICE_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "alac_kernels.h"
+
+namespace alacdev {
+
+
+constexpr int RING_BYTES = 1024;          // per-row LDS ring
+constexpr int RING_MASK = RING_BYTES - 1;
+// a refill chunk is LPS lanes x 16 B, LPS = lanes cooperating on one stream
+constexpr int BUFFER_SIZE = 16384;        // AlacFile.cs:28
+
+// LDS hand-off between lanes of ONE wave: a wave's LDS operations execute in order, so only the
+// compiler has to be kept from reordering them.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// LDS hand-off between the waves of a workgroup.
+__device__ __forceinline__ void wg_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// ---- C# int semantics: wrapping add/sub/mul ---------------------------------------------------------
+__device__ __forceinline__ int wadd(int a, int b) { return (int)((uint32_t)a + (uint32_t)b); }
+__device__ __forceinline__ int wsub(int a, int b) { return (int)((uint32_t)a - (uint32_t)b); }
+__device__ __forceinline__ int wmul(int a, int b) { return (int)((uint32_t)a * (uint32_t)b); }
+
+// ---- DPP helpers (row = 16 lanes) --------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ int dpp0(int v) {  // out-of-row / invalid source lanes read 0
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+constexpr int DPP_QUAD_1032 = 0xB1, DPP_QUAD_2301 = 0x4E, DPP_ROW_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140;
+constexpr int DPP_ROW_SHL1 = 0x101, DPP_ROW_SHL2 = 0x102, DPP_ROW_SHL4 = 0x104, DPP_ROW_SHL8 = 0x108;
+constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_ROR1 = 0x121;
+
+__device__ __forceinline__ int row_allreduce_add(int v) {
+    v = wadd(v, dpp0<DPP_QUAD_1032>(v));
+    v = wadd(v, dpp0<DPP_QUAD_2301>(v));
+    v = wadd(v, dpp0<DPP_ROW_HALF_MIRROR>(v));
+    v = wadd(v, dpp0<DPP_ROW_MIRROR>(v));
+    return v;
+}
+// inclusive suffix sum inside the row: lane l gets sum over lanes l..15
+__device__ __forceinline__ int row_suffix_scan(int v) {
+    v = wadd(v, dpp0<DPP_ROW_SHL1>(v));
+    v = wadd(v, dpp0<DPP_ROW_SHL2>(v));
+    v = wadd(v, dpp0<DPP_ROW_SHL4>(v));
+    v = wadd(v, dpp0<DPP_ROW_SHL8>(v));
+    return v;
+}
+
+// ---- slow-path bit access straight from global memory (header, shift bytes, escape samples) ----
+__device__ __forceinline__ uint32_t load_be32(const uint8_t* base, int64_t byte_off, int64_t limit) {
+    // byte_off is 4-aligned relative to a 16-aligned base
+    if (byte_off < 0 || byte_off + 4 > limit) return 0;
+    return __builtin_bswap32(*reinterpret_cast<const uint32_t*>(base + byte_off));
+}
+// nbits in 1..32, MSB-first field starting at bit `bitpos`
+__device__ __forceinline__ uint32_t peek_bits(const uint8_t* base, int64_t limit, uint32_t bitpos, int nbits) {
+    int64_t d = (int64_t)(bitpos >> 5) * 4;
+    uint32_t hi = load_be32(base, d, limit), lo = load_be32(base, d + 4, limit);
+    uint64_t w = ((uint64_t)hi << 32) | lo;
+    w <<= (bitpos & 31);
+    return (uint32_t)(w >> 32) >> (32 - nbits);
+}
+
+// ---- Rice reader state (row-uniform) -------------------------------------------------------------
+struct Rice {
+    uint32_t w0, w1, w2;  // three consecutive big-endian dwords; w2 is the prefetched one
+    int rem;              // unconsumed bits left in w0, 0..31
+    uint32_t next;        // byte offset (from the aligned packet base) of the dword after w2
+    int hist;             // history            (AlacFile.cs:216)
+    int signmod;          // signModifier       (:218)
+    int zrun;             // zeros still to emit from the last run (:238-245)
+};
+
+__device__ __forceinline__ uint32_t rice_window(const Rice& s) {
+    return __builtin_amdgcn_alignbit(s.w0, s.w1, s.rem);
+}
+__device__ __forceinline__ void rice_advance(Rice& s, int c, const uint32_t* ring) {
+    int rem = s.rem - c;
+    bool adv = rem < 0;
+    s.rem = rem & 31;
+    s.w0 = adv ? s.w1 : s.w0;
+    s.w1 = adv ? s.w2 : s.w1;
+    s.next += adv ? 4u : 0u;
+    s.w2 = ring[((s.next - 4u) & RING_MASK) >> 2];
+}
+__device__ __forceinline__ uint32_t rice_bitpos(const Rice& s) { return (s.next - 12u) * 8u + 32u - (uint32_t)s.rem; }
+
+// One EntropyDecodeValue (AlacFile.cs:193-212).  m = ((1<<k)-1) & mask, escape_bits = rss or 16.
+__device__ __forceinline__ uint32_t rice_symbol(Rice& s, int k, uint32_t m, int escape_bits, const uint32_t* ring) {
+    uint32_t win = rice_window(s);
+    uint32_t x = (uint32_t)__clz((int)~win);  // leading ones; 32 when win is all ones
+    uint32_t v;
+    if (x > 8) {                              // nine 1s: raw value follows (:198-202)
+        rice_advance(s, 9, ring);
+        win = rice_window(s);
+        v = win >> (32 - escape_bits);
+        rice_advance(s, escape_bits, ring);
+    } else {
+        uint32_t e = (win << (x + 1)) >> (32 - k);      // Readbits(k)            (:205)
+        uint32_t big = e > 1 ? 1u : 0u;
+        v = __umul24(x, m) + (big ? e - 1 : 0);         // (:206-208)
+        rice_advance(s, (int)(x + k + big), ring);      // Unreadbits(1) when e <= 1 (:210)
+    }
+    return v;
+}
+
+struct RiceCfg {
+    int kmod;
+    uint32_t kmask;
+    int hist_mult;
+    int rss;
+};
+
+// One output residual of EntropyRiceDecode (AlacFile.cs:219-251).  `remaining` = outputSize-1-outputCount.
+// Sets *flags bit0 when a zero run would leave the reference's 16384-entry scratch, bit1 when history went negative.
+__device__ __forceinline__ int rice_step(Rice& s, const RiceCfg& c, int remaining, int sample_idx, int* flags,
+                                         const uint32_t* ring) {
+    if (s.zrun > 0) {
+        s.zrun--;
+        return 0;
+    }
+    int t = (s.hist >> 9) + 3;
+    int k = 31 - __clz(t);
+    k = k < c.kmod ? k : c.kmod;                                             // :221-222
+    uint32_t dv = rice_symbol(s, k, (1u << k) - 1u, c.rss, ring) + (uint32_t)s.signmod;  // :224
+    s.signmod = 0;
+    int r = (int)(dv >> 1) ^ -(int)(dv & 1u);                                // :225-226 (dv >= 0)
+    int h = s.hist;
+    h = (int)dv > 0xFFFF ? 0xFFFF : wsub(wadd(h, wmul((int)dv, c.hist_mult)), wmul(h, c.hist_mult) >> 9);  // :229
+    if (h < 128 && remaining > 0) {                                          // :231
+        if (h < 0) { *flags |= 2; h = 0; }
+        s.signmod = 1;
+        int k2 = (h == 0 ? 40 : __clz(h)) + ((h + 16) >> 6) - 24;           // :234 (clz(0) == 40 quirk)
+        uint32_t bs = rice_symbol(s, k2, ((1u << (k2 & 31)) - 1u) & c.kmask, 16, ring);  // :236
+        if ((uint32_t)sample_idx + bs > (uint32_t)(BUFFER_SIZE - 1)) *flags |= 1;        // :242 would throw
+        s.zrun = bs > 0x7FFFFFFFu ? 0x7FFFFFFF : (int)bs;
+        if (bs > 0xFFFF) s.signmod = 0;                                      // :246
+        h = 0;                                                               // :248
+    }
+    s.hist = h;
+    return r;
+}
+
+// ---- per-row LDS ring ------------------------------------------------------------------------------
+// Tops the ring up with 256-byte chunks while there is room in front of the oldest live dword.
+template <int LPS>
+__device__ __forceinline__ void ring_fill(uint32_t* ring, uint32_t& filled, uint32_t next, const uint8_t* base,
+                                          int64_t limit, int l, bool enable) {
+    constexpr uint32_t FILL_CHUNK = LPS * 16;
+    while (true) {
+        bool need = enable && (filled + FILL_CHUNK <= (next - 12u) + RING_BYTES);
+        if (!__builtin_amdgcn_ballot_w64(need)) break;
+        if (need) {
+            int64_t off = (int64_t)filled + l * 16;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (off + 16 <= limit) v = *reinterpret_cast<const uint4*>(base + off);
+            uint4 o = make_uint4(__builtin_bswap32(v.x), __builtin_bswap32(v.y), __builtin_bswap32(v.z),
+                                 __builtin_bswap32(v.w));
+            *reinterpret_cast<uint4*>(&ring[(off & RING_MASK) >> 2]) = o;
+            filled += FILL_CHUNK;
+        }
+    }
+}
+
+template <int LPS>
+__device__ __forceinline__ void rice_init(Rice& s, uint32_t& filled, uint32_t startbit, int init_hist, uint32_t* ring,
+                                          const uint8_t* base, int64_t limit, int l, bool enable) {
+    constexpr uint32_t FILL_CHUNK = LPS * 16;
+    uint32_t p = startbit - 1u;   // startbit >= 23 always
+    uint32_t d = (p >> 5) * 4u;   // byte offset of the dword holding bit startbit-1
+    s.rem = 31 - (int)(p & 31u);
+    s.next = d + 12u;
+    s.hist = init_hist;
+    s.signmod = 0;
+    s.zrun = 0;
+    filled = d & ~(uint32_t)(FILL_CHUNK - 1);
+    wave_sync();
+    ring_fill<LPS>(ring, filled, s.next, base, limit, l, enable);
+    wave_sync();
+    s.w0 = ring[((d) & RING_MASK) >> 2];
+    s.w1 = ring[((d + 4u) & RING_MASK) >> 2];
+    s.w2 = ring[((d + 8u) & RING_MASK) >> 2];
+}
+
+// ---- FIR state: tap j = l + 16*t lives in lane l, register t ---------------------------------------
+template <int TPL>
+struct Fir {
+    int hist[TPL];  // out[i-1-j]
+    int coef[TPL];  // predictorCoefTable[j] (0 for j >= N)
+    int base;       // out[i-1-N]            (row-uniform)
+    int prev;       // out[i-1]              (row-uniform)
+};
+
+template <int TPL>
+__device__ __forceinline__ int fir_step(Fir<TPL>& f, int err, int i, int N, int q, int rnd, int rss, int l,
+                                        int rowlane0) {
+    int out;
+    if (i == 0 || N == 0) {
+        out = err;                                            // :260-267, first sample copies
+    } else if (i <= N || N == 31) {
+        out = __builtin_amdgcn_sbfe(wadd(f.prev, err), 0, rss);  // :268-293
+    } else {
+        int acc = 0;
+        int d[TPL];
+#pragma unroll
+        for (int t = 0; t < TPL; t++) {
+            d[t] = wsub(f.hist[t], f.base);                   // :303
+            acc = wadd(acc, wmul(d[t], f.coef[t]));
+        }
+        int sum = row_allreduce_add(acc);
+        int pred = wadd(wadd(rnd, sum) >> q, f.base);         // :306-308
+        out = __builtin_amdgcn_sbfe(wadd(pred, err), 0, rss);  // :309-310
+        if (err != 0) {                                       // :312-332 sign-LMS, parallel form
+            // tap p is visited in order p = N-1 .. 0 while the running error keeps its sign; with
+            // E = |err| and c_p = the magnitude tap p takes off it, tap p is visited iff
+            // E - sum_{p' > p} c_p' > 0.
+            const int sg = err > 0 ? 1 : -1;
+            const uint32_t E = (uint32_t)(err > 0 ? err : -err);
+            const int rnde = err < 0 ? (1 << q) - 1 : 0;      // (-a) >> q == -((a + 2^q - 1) >> q)
+            uint32_t c[TPL];
+#pragma unroll
+            for (int t = 0; t < TPL; t++) {
+                int a = d[t] < 0 ? -d[t] : d[t];
+                int j = l + 16 * t;
+                uint32_t w = j < N ? (uint32_t)(N - j) : 0u;
+                uint32_t cc = ((uint32_t)(a + rnde) >> q) * w;
+                c[t] = cc < (1u << 26) ? cc : (1u << 26);     // clamp: keeps the scan from wrapping, decisions unchanged
+            }
+            uint32_t upper = 0;  // contribution of the taps in higher registers (visited first)
+#pragma unroll
+            for (int t = TPL - 1; t >= 0; t--) {
+                uint32_t incl = (uint32_t)row_suffix_scan((int)c[t]);
+                uint32_t excl = incl - c[t] + upper;
+                int j = l + 16 * t;
+                bool visit = (j < N) && (E > excl);
+                int sd = d[t] > 0 ? 1 : (d[t] < 0 ? -1 : 0);
+                f.coef[t] += visit ? sg * sd : 0;             // coef[p] -= sign, sign = +-sgn(base - hist) (:325-327)
+                if (t > 0) upper += (uint32_t)row_allreduce_add((int)c[t]);
+            }
+        }
+    }
+    // slide the history: tap N-1 becomes the next base, out enters at tap 0
+    if (N >= 1 && N <= 30) {
+        int src = (TPL > 1 && N > 16) ? f.hist[TPL - 1] : f.hist[0];
+        f.base = __shfl(src, rowlane0 + ((N - 1) & 15), 64);
+    }
+#pragma unroll
+    for (int t = TPL - 1; t >= 1; t--) {
+        int carry = __builtin_amdgcn_update_dpp(0, f.hist[t - 1], DPP_ROW_ROR1, 0xF, 0xF, false);
+        f.hist[t] = __builtin_amdgcn_update_dpp(carry, f.hist[t], DPP_ROW_SHR1, 0xF, 0xF, false);
+    }
+    f.hist[0] = __builtin_amdgcn_update_dpp(out, f.hist[0], DPP_ROW_SHR1, 0xF, 0xF, false);
+    f.prev = out;
+    return out;
+}
+
+// Everything a lane knows about its packet / stream after the header parse.
+struct Meta {
+    const uint8_t* base;   // 16-byte aligned-down packet start
+    int64_t limit;         // readable bytes from base
+    uint32_t size_bits_end; // bit position (from base) one past the packet's last bit
+    int n;                 // samples per channel
+    int status;
+    int stereo, esc, ub, ss, nc, rss;
+    int mixshift, mixweight;
+    int N, q, rnd, ricemod, predtype;  // this row's channel
+    uint32_t coefbit;      // bit position of this channel's first coefficient
+    uint32_t ubit;         // bit position of the shift-byte block
+    uint32_t ricebit;      // bit position where Rice stream A starts
+    uint32_t rawbit;       // bit position of the first raw sample (escape packets)
+    int out_bytes;
+};
+
+
+// Header parse (AlacFile.cs:435-475 / :584-641) for the stream (pkt, chan).  Every lane that needs a
+// stream's facts calls this itself (a handful of cached loads).  cfg receives the stream cfg.
+__device__ __forceinline__ Meta parse_meta(const alac_decode_params& p, uint32_t pkt, int chan, bool valid,
+                                           alacgpu_cfg_dev& cfg) {
+    Meta m;
+    m.base = p.blob;
+    m.limit = 0;
+    m.size_bits_end = 0;
+    m.n = 0;
+    m.status = 0;
+    m.stereo = m.esc = m.ub = 0;
+    m.ss = 16;
+    m.nc = 1;
+    m.rss = 16;
+    m.mixshift = m.mixweight = 0;
+    m.N = m.q = m.ricemod = m.predtype = 0;
+    m.rnd = 0;
+    m.coefbit = m.ubit = m.ricebit = m.rawbit = 64;
+    m.out_bytes = 0;
+    cfg = p.cfgs[0];
+
+    if (valid) {
+        uint32_t ci = p.cfg_idx ? p.cfg_idx[pkt] : 0u;
+        bool badcfg = ci >= p.n_cfgs;
+        if (!badcfg) cfg = p.cfgs[ci];
+        const uint64_t off = p.offsets[pkt];
+        const uint32_t size = p.sizes[pkt];
+        const uint32_t mis = (uint32_t)(off & 15u);
+        m.base = p.blob + (off - mis);
+        m.limit = (int64_t)p.blob_limit - (int64_t)(off - mis);
+        const uint32_t bit0 = mis * 8u;
+        m.size_bits_end = bit0 + size * 8u;
+        m.ss = cfg.sample_size;
+        m.nc = cfg.num_channels;
+        const int ctor_ss = cfg.ctor_sample_size ? cfg.ctor_sample_size : cfg.sample_size;
+        const int bytespersample = (ctor_ss / 8) * m.nc;                       // AlacFile.cs:19
+        const uint32_t channels = peek_bits(m.base, m.limit, bit0, 3);         // :435
+        const uint32_t hassize = peek_bits(m.base, m.limit, bit0 + 19, 1);     // :444,:586
+        m.ub = (int)peek_bits(m.base, m.limit, bit0 + 20, 2);                  // :445,:587
+        m.esc = (int)peek_bits(m.base, m.limit, bit0 + 22, 1);                 // :446,:588
+        m.n = (int)cfg.max_samples_per_frame;                                  // :430
+        uint32_t hdr_end = bit0 + 23;
+        if (hassize) {
+            m.n = (int)peek_bits(m.base, m.limit, bit0 + 23, 32);              // :451,:593
+            hdr_end += 32;
+        }
+        m.out_bytes = (int)((uint32_t)m.n * (uint32_t)bytespersample);         // :436,:452,:718
+        m.stereo = channels == 1;
+        if (badcfg) m.status = ALACGPU_ST_UNSUPPORTED_PARAMS_D;
+        else if (channels > 1) { m.status = ALACGPU_ST_UNSUPPORTED_ELEMENT_D; m.n = (int)cfg.max_samples_per_frame;
+                                 m.out_bytes = (int)((uint32_t)m.n * (uint32_t)bytespersample); }
+        else if (m.ss != 16 && m.ss != 24) m.status = ALACGPU_ST_UNSUPPORTED_SAMPLE_SIZE_D;
+        else if (m.stereo && m.nc < 2) m.status = ALACGPU_ST_UNSUPPORTED_ELEMENT_D;
+        else if (m.nc < 1 || m.nc > 2) m.status = ALACGPU_ST_UNSUPPORTED_ELEMENT_D;
+        else if (m.n <= 0 || m.n > BUFFER_SIZE || (uint64_t)m.n * (uint64_t)m.nc > p.slot_ints)
+            m.status = ALACGPU_ST_BAD_SAMPLE_COUNT_D;
+        else if (m.ss - m.ub * 8 < 8) m.status = ALACGPU_ST_UNSUPPORTED_PARAMS_D;
+        m.rawbit = hdr_end;
+        if (m.status == 0) {
+            if (m.esc) {
+                m.ub = 0;                                                       // :525,:697
+            } else {
+                m.rss = m.ss - m.ub * 8 + (m.stereo ? 1 : 0);                   // :454,:596
+                if (m.stereo) {
+                    m.mixshift = (int)peek_bits(m.base, m.limit, hdr_end, 8);       // :599
+                    m.mixweight = (int)peek_bits(m.base, m.limit, hdr_end + 8, 8);  // :600 (unsigned)
+                }
+                uint32_t pa = hdr_end + 16;
+                uint32_t ha = peek_bits(m.base, m.limit, pa, 16);               // :461-464 / :602-605
+                int Na = (int)(ha & 31u);
+                uint32_t pb = pa + 16 + 16u * Na;
+                uint32_t hb = 0;
+                int Nb = 0;
+                if (m.stereo) {
+                    hb = peek_bits(m.base, m.limit, pb, 16);                    // :618-621
+                    Nb = (int)(hb & 31u);
+                }
+                uint32_t hh = chan == 0 ? ha : hb;
+                m.predtype = (int)(hh >> 12) & 15;
+                m.q = (int)(hh >> 8) & 15;
+                m.ricemod = (int)(hh >> 5) & 7;
+                m.N = chan == 0 ? Na : Nb;
+                m.rnd = (int)(1u << ((m.q - 1) & 31));                          // 1 << (q-1), C# shift masking (:306)
+                m.coefbit = (chan == 0 ? pa : pb) + 16;
+                m.ubit = m.stereo ? pb + 16 + 16u * Nb : pb;
+                m.ricebit = m.ubit + (uint32_t)m.n * (m.stereo ? 2u : 1u) * 8u * (uint32_t)m.ub;  // :476-482 / :634-641
+            }
+        }
+    }
+
+    return m;
+}
+
+}  // namespace alacdev
+#endif

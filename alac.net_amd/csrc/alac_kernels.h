@@ -40,7 +40,10 @@ struct alac_decode_params {
 };
 
 #ifdef __HIPCC__
-extern "C" __global__ void alac_decode_packets_kernel(alac_decode_params p);
+extern "C" __global__ void alac_decode_packets_kernel(alac_decode_params p);   // v1: fused, 2 packets / 64-thread WG
+extern "C" __global__ void alac_decode_split1_kernel(alac_decode_params p);    // v2: 1 entropy + 1 recon wave, 2 packets
+extern "C" __global__ void alac_decode_split2_kernel(alac_decode_params p);    // v2: 1 entropy + 2 recon waves, 4 packets
+extern "C" __global__ void alac_decode_split4_kernel(alac_decode_params p);    // v2: 1 entropy + 4 recon waves, 8 packets
 #endif
 
 // packets decoded per workgroup by alac_decode_packets_kernel

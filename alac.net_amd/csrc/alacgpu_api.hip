@@ -21,6 +21,7 @@ struct alacgpu_ctx {
     hipStream_t stream = nullptr;      // used by the host-buffer entry points
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    int variant = 0;                   // 0 auto, 1 fused (v1), 2/3/4 split with 1/2/4 reconstruction waves
     // grow-only device workspace for the host-buffer entry points
     void* d_ws = nullptr;
     size_t ws_bytes = 0;
@@ -55,9 +56,23 @@ int ensure_ws(alacgpu_ctx* ctx, size_t bytes) {
 
 int launch(alacgpu_ctx* ctx, const alac_decode_params& p, hipStream_t stream) {
     if (p.n_packets == 0) return ALACGPU_OK;
-    const uint32_t grid = (p.n_packets + ALAC_PACKETS_PER_WG - 1) / ALAC_PACKETS_PER_WG;
+    int variant = ctx->variant;
+    if (variant == 0) variant = 3;  // auto: split kernel, 1 entropy + 2 reconstruction waves (4 packets / WG)
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
-    hipLaunchKernelGGL(alac_decode_packets_kernel, dim3(grid), dim3(ALAC_WG_THREADS), 0, stream, p);
+    switch (variant) {
+    case 1:
+        hipLaunchKernelGGL(alac_decode_packets_kernel, dim3((p.n_packets + 1) / 2), dim3(64), 0, stream, p);
+        break;
+    case 2:
+        hipLaunchKernelGGL(alac_decode_split1_kernel, dim3((p.n_packets + 1) / 2), dim3(128), 0, stream, p);
+        break;
+    case 4:
+        hipLaunchKernelGGL(alac_decode_split4_kernel, dim3((p.n_packets + 7) / 8), dim3(320), 0, stream, p);
+        break;
+    default:
+        hipLaunchKernelGGL(alac_decode_split2_kernel, dim3((p.n_packets + 3) / 4), dim3(192), 0, stream, p);
+        break;
+    }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
     ctx->timed = true;
@@ -129,6 +144,7 @@ int alacgpu_create(const alacgpu_cfg* cfgs, uint32_t n_cfgs, int device, alacgpu
     if (!ctx) return ALACGPU_ERR_NO_MEMORY;
     ctx->device = device;
     ctx->n_cfgs = n_cfgs;
+    if (const char* v = std::getenv("ALACGPU_KERNEL_VARIANT")) ctx->variant = std::atoi(v) >= 0 && std::atoi(v) <= 4 ? std::atoi(v) : 0;
     int rc = ALACGPU_OK;
     do {
         if (hipSetDevice(device) != hipSuccess) { rc = ALACGPU_ERR_NO_DEVICE; break; }
@@ -292,6 +308,12 @@ int alacgpu_decode_frame(alacgpu_ctx* ctx, uint32_t cfg_index, const uint8_t* in
     }
     std::free(pcm);
     return rc;
+}
+
+int alacgpu_set_kernel_variant(alacgpu_ctx* ctx, int variant) {
+    if (!ctx || variant < 0 || variant > 4) return ALACGPU_ERR_BAD_ARG;
+    ctx->variant = variant;
+    return ALACGPU_OK;
 }
 
 float alacgpu_last_kernel_ms(alacgpu_ctx* ctx) {

@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=2, help="BASELINE.json config number (2..5)")
     ap.add_argument("--packets", type=int, default=None, help="packets per GPU (default: the config's batch)")
+    ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 auto, 1 fused, 2/3/4 split)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-allgather", action="store_true")
     args = ap.parse_args()
@@ -81,6 +82,7 @@ def main():
     d_st = torch.full((n_packets,), -1, dtype=torch.int32, device=dev)
 
     ctx = pkg.AlacGpuContext(b["stream_cfgs"], device=local_rank)
+    ctx.set_kernel_variant(args.variant)
     stream = torch.cuda.current_stream(dev)
 
     def step():
@@ -189,7 +191,8 @@ def main():
                        "samples_per_step_per_gpu": samples_per_step, "parallelism": f"packet-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                         "kernel": "alac_decode_packets_kernel", "kernel_ms": round(kernel_ms, 4),
+                         "kernel": {0: "alac_decode_split2_kernel", 1: "alac_decode_packets_kernel", 2: "alac_decode_split1_kernel",
+                                    3: "alac_decode_split2_kernel", 4: "alac_decode_split4_kernel"}[args.variant], "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": algo_bytes},
             "cpu_baseline": cpu_baseline,
             "parity_vs_oracle": parity, "status_ok": status_ok, "allgather_ms": allgather_ms,

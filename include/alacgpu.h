@@ -119,6 +119,11 @@ size_t alacgpu_format_samples(int bytes_per_sample, const int32_t* ref_ints, int
  * on the launch stream (milliseconds; < 0 if unavailable).  Synchronises the stream. */
 float alacgpu_last_kernel_ms(alacgpu_ctx* ctx);
 
+/* Tuning / A-B knob (no effect on results): 0 = auto (default), 1 = fused single-wave kernel,
+ * 2 / 3 / 4 = split kernel with 1 / 2 / 4 reconstruction waves per workgroup.  Also settable with the
+ * environment variable ALACGPU_KERNEL_VARIANT at create time. */
+int alacgpu_set_kernel_variant(alacgpu_ctx* ctx, int variant);
+
 const char* alacgpu_strerror(int rc);
 const char* alacgpu_status_string(int status);
 const char* alacgpu_last_error(alacgpu_ctx* ctx);

@@ -19,8 +19,12 @@ def pkg():
     return p
 
 
-def run_both(pkg, oracle, b, n_threads=8):
+VARIANTS = [1, 2, 3, 4]
+
+
+def run_both(pkg, oracle, b, n_threads=8, variant=0):
     with pkg.AlacGpuContext(b["stream_cfgs"], device=0) as ctx:
+        ctx.set_kernel_variant(variant)
         g = ctx.decode_batch(b["blob"], b["offsets"], b["sizes"], b["cfg_idx"], b["slot_ints"])
     o = oracle.decode_batch(oracle.make_cfgs(b["stream_cfgs"]), b["blob"], b["offsets"], b["sizes"], b["cfg_idx"],
                             b["slot_ints"], n_threads=n_threads)
@@ -43,10 +47,11 @@ def assert_same(g, o, cfgs=None, cfg_idx=None):
                                  f"gpu {gp[p, bad[:8]]} oracle {op[p, bad[:8]]}")
 
 
+@pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("cfg,n", [(2, 64), (3, 24), (4, 64), (5, 256)])
-def test_baseline_configs_small(pkg, oracle, synth, cfg, n):
+def test_baseline_configs_small(pkg, oracle, synth, cfg, n, variant):
     b = synth.make_config_batch(cfg, n_packets=n, want_pcm=True)
-    g, o = run_both(pkg, oracle, b)
+    g, o = run_both(pkg, oracle, b, variant=variant)
     assert_same(g, o, b["stream_cfgs"], b["cfg_idx"])
     # and both equal the encoder's source PCM (independent round trip)
     d = b["descs"]
@@ -61,9 +66,11 @@ def test_baseline_configs_small(pkg, oracle, synth, cfg, n):
                 assert np.array_equal(got, src), f"packet {p} != source PCM"
 
 
-def test_hand_kats_on_gpu(pkg):
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_hand_kats_on_gpu(pkg, variant):
     # the same hand-derived vectors that pin the oracle (tests/test_oracle_kat.py), straight on the GPU
     with pkg.AlacGpuContext([(4096, 16, 40, 10, 14, 2), (4096, 16, 40, 10, 14, 1), (4096, 24, 40, 10, 14, 2)]) as ctx:
+        ctx.set_kernel_variant(variant)
         k1 = pack([(3, 1), (4, 0), (12, 0), (1, 1), (2, 0), (1, 1), (32, 2), (16, 1), (16, 0xFFFF), (16, 0x7FFF), (16, 0x8000)])
         k2 = pack([(3, 0), (4, 0), (12, 0), (1, 1), (2, 0), (1, 0), (32, 3), (8, 0), (8, 0), (4, 0), (4, 0), (3, 4), (5, 0),
                    "110", "0", "10", "0"])
@@ -85,7 +92,8 @@ def test_hand_kats_on_gpu(pkg):
         assert s == 0 and out_bytes == 6 and ref[:6].tolist() == [0xAB, 0x34, 0x12, 0xCD, 0, 0]
 
 
-def test_unaligned_offsets_and_odd_batch(pkg, oracle, synth):
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_unaligned_offsets_and_odd_batch(pkg, oracle, synth, variant):
     b = synth.make_config_batch(2, n_packets=7, want_pcm=True)
     # re-pack the packets back to back at odd byte offsets
     parts, offs, pos = [], [], 3
@@ -97,12 +105,13 @@ def test_unaligned_offsets_and_odd_batch(pkg, oracle, synth):
     b2 = dict(b)
     b2["blob"] = np.frombuffer(bytes(blob), dtype=np.uint8)
     b2["offsets"] = np.array(offs, dtype=np.uint64)
-    g, o = run_both(pkg, oracle, b2)
+    g, o = run_both(pkg, oracle, b2, variant=variant)
     assert_same(g, o, b["stream_cfgs"], None)
     assert np.array_equal(g[0], b["pcm"])
 
 
-def test_statuses(pkg, oracle, synth):
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_statuses(pkg, oracle, synth, variant):
     d = synth.packet_descs(6, n=256, max_samples_per_frame=4096)
     d["channels_field"][0] = 2        # unsupported element
     d["pred_type"][1] = [0, 3]        # unhandled prediction type (stereo B)
@@ -113,6 +122,6 @@ def test_statuses(pkg, oracle, synth):
     b.update(stream_cfgs=[(4096, 16, 40, 10, 14, 2)], cfg_idx=None)
     # truncate the last packet: bitstream overrun
     b["sizes"][5] = b["sizes"][5] // 2
-    g, o = run_both(pkg, oracle, b)
+    g, o = run_both(pkg, oracle, b, variant=variant)
     assert o[3].tolist() == [1, 3, 0, 0, 0, 5]
     assert_same(g, o, b["stream_cfgs"], None)
