@@ -83,7 +83,26 @@ struct Rice {
     int hist;             // history            (AlacFile.cs:216)
     int signmod;          // signModifier       (:218)
     int zrun;             // zeros still to emit from the last run (:238-245)
+    uint32_t nforce;      // ~0 when the lane may take the fast step, 0 when it needs the generic one
+                          // (inside a zero run, or signModifier pending)
 };
+
+// ---- single-instruction helpers the compiler does not pick by itself --------------------------------
+__device__ __forceinline__ uint32_t ffbh_u32(uint32_t x) {  // count leading zeros; 0xFFFFFFFF for x == 0
+    uint32_t r;
+    asm("v_ffbh_u32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+__device__ __forceinline__ uint32_t bfm0(uint32_t k) {  // (1 << k) - 1
+    uint32_t r;
+    asm("v_bfm_b32 %0, %1, 0" : "=v"(r) : "v"(k));
+    return r;
+}
+__device__ __forceinline__ uint32_t and_not(uint32_t b, uint32_t m) {  // b & ~m
+    uint32_t r;
+    asm("v_bfi_b32 %0, %1, 0, %2" : "=v"(r) : "v"(m), "v"(b));
+    return r;
+}
 
 __device__ __forceinline__ uint32_t rice_window(const Rice& s) {
     return __builtin_amdgcn_alignbit(s.w0, s.w1, s.rem);
@@ -125,35 +144,81 @@ struct RiceCfg {
     int rss;
 };
 
-// One output residual of EntropyRiceDecode (AlacFile.cs:219-251).  `remaining` = outputSize-1-outputCount.
-// Sets *flags bit0 when a zero run would leave the reference's 16384-entry scratch, bit1 when history went negative.
+// The "compressed blocks of 0" branch of EntropyRiceDecode (AlacFile.cs:231-249), taken right after a
+// value whose updated history fell below 128 (and a sample remains).  s.hist holds that history.
+__device__ __forceinline__ void rice_run_part(Rice& s, const RiceCfg& c, int sample_idx, int* flags,
+                                              const uint32_t* ring) {
+    int h = s.hist;
+    if (h < 0) { *flags |= 2; h = 0; }
+    s.signmod = 1;                                                            // :233
+    int k2 = (h == 0 ? 40 : __clz(h)) + ((h + 16) >> 6) - 24;                // :234 (clz(0) == 40 quirk)
+    uint32_t bs = rice_symbol(s, k2, ((1u << (k2 & 31)) - 1u) & c.kmask, 16, ring);  // :236
+    if ((uint32_t)sample_idx + bs > (uint32_t)(BUFFER_SIZE - 1)) *flags |= 1;        // :242 would throw
+    s.zrun = bs > 0x7FFFFFFFu ? 0x7FFFFFFF : (int)bs;
+    if (bs > 0xFFFF) s.signmod = 0;                                           // :246
+    s.hist = 0;                                                               // :248
+    s.nforce = 0;
+}
+
+// One output residual of EntropyRiceDecode (AlacFile.cs:219-251), every case.  `remaining` =
+// outputSize-1-outputCount.  Sets *flags bit0 when a zero run would leave the reference's 16384-entry
+// scratch, bit1 when history went negative.
 __device__ __forceinline__ int rice_step(Rice& s, const RiceCfg& c, int remaining, int sample_idx, int* flags,
                                          const uint32_t* ring) {
+    int r = 0;
     if (s.zrun > 0) {
         s.zrun--;
-        return 0;
+    } else {
+        int t = (s.hist >> 9) + 3;
+        int k = 31 - __clz(t);
+        k = k < c.kmod ? k : c.kmod;                                             // :221-222
+        uint32_t dv = rice_symbol(s, k, (1u << k) - 1u, c.rss, ring) + (uint32_t)s.signmod;  // :224
+        s.signmod = 0;
+        r = (int)(dv >> 1) ^ -(int)(dv & 1u);                                    // :225-226 (dv >= 0)
+        int h = s.hist;
+        h = (int)dv > 0xFFFF ? 0xFFFF : wsub(wadd(h, wmul((int)dv, c.hist_mult)), wmul(h, c.hist_mult) >> 9);  // :229
+        s.hist = h;
+        if (h < 128 && remaining > 0) rice_run_part(s, c, sample_idx, flags, ring);  // :231
     }
-    int t = (s.hist >> 9) + 3;
-    int k = 31 - __clz(t);
-    k = k < c.kmod ? k : c.kmod;                                             // :221-222
-    uint32_t dv = rice_symbol(s, k, (1u << k) - 1u, c.rss, ring) + (uint32_t)s.signmod;  // :224
-    s.signmod = 0;
-    int r = (int)(dv >> 1) ^ -(int)(dv & 1u);                                // :225-226 (dv >= 0)
-    int h = s.hist;
-    h = (int)dv > 0xFFFF ? 0xFFFF : wsub(wadd(h, wmul((int)dv, c.hist_mult)), wmul(h, c.hist_mult) >> 9);  // :229
-    if (h < 128 && remaining > 0) {                                          // :231
-        if (h < 0) { *flags |= 2; h = 0; }
-        s.signmod = 1;
-        int k2 = (h == 0 ? 40 : __clz(h)) + ((h + 16) >> 6) - 24;           // :234 (clz(0) == 40 quirk)
-        uint32_t bs = rice_symbol(s, k2, ((1u << (k2 & 31)) - 1u) & c.kmask, 16, ring);  // :236
-        if ((uint32_t)sample_idx + bs > (uint32_t)(BUFFER_SIZE - 1)) *flags |= 1;        // :242 would throw
-        s.zrun = bs > 0x7FFFFFFFu ? 0x7FFFFFFF : (int)bs;
-        if (bs > 0xFFFF) s.signmod = 0;                                      // :246
-        h = 0;                                                               // :248
-    }
-    s.hist = h;
+    s.nforce = (s.zrun > 0 || s.signmod != 0) ? 0u : 0xFFFFFFFFu;
     return r;
 }
+
+// Speculative fast step: the common case of rice_step (no pending zero run / signModifier, unary prefix
+// <= 8, updated history >= 128) as straight-line code with no branch and no exec masking.  It does NOT
+// check those conditions: it records them in xmax / hmin so that the caller can validate a whole unit of
+// steps afterwards and, if any lane left the common case, restore its snapshot and redo the unit with
+// rice_step.  A lane that has left the common case keeps running on garbage; that is harmless (LDS ring
+// reads are address-masked, nothing else is touched).
+template <bool WANT_R>
+__device__ __forceinline__ int rice_spec_step(Rice& s, const RiceCfg& c, const uint32_t* ring, uint32_t& xmax,
+                                              int& hmin) {
+    const uint32_t win = rice_window(s);
+    const uint32_t x = (uint32_t)__builtin_clz(~win | 0x00400000u);          // leading ones, capped at 9 (:196)
+    xmax = max(xmax, x);
+    // (hist >> 9) + 3 == (hist + 1536) >> 9 for hist >= 0, so k = min(31 - clz(..), kmod) = min(22 - clz(hist + 1536), kmod)
+    const int k = min(22 - __builtin_clz((uint32_t)(s.hist + 1536)), c.kmod);      // :221-222
+    const uint32_t e = __builtin_amdgcn_ubfe(win, (uint32_t)(31 - k) - x, (uint32_t)k);  // Readbits(k) (:205)
+    const uint32_t m = __builtin_amdgcn_ubfe(0xFFFFFFFFu, 0u, (uint32_t)k);        // (1 << k) - 1
+    const uint32_t v = __umul24(x, m) + (e > 1u ? e - 1u : 0u);                    // :206-208
+    const int rem2 = s.rem - (int)(x + (uint32_t)k) - (e > 1u ? 1 : 0);      // bits used: x+1+k, minus the un-read one (:210)
+    int r = 0;
+    if (WANT_R) r = (int)(v >> 1) ^ -(int)(v & 1u);                          // :225-226
+    const int h = s.hist;
+    int hx = (int)(__umul24(v, (uint32_t)c.hist_mult) + (uint32_t)h) - (wmul(h, c.hist_mult) >> 9);
+    asm volatile("" : "+v"(hx));   // keep this unconditional: a select, not an exec-masked branch
+    const int hn = (int)v > 0xFFFF ? 0xFFFF : hx;                            // :229
+    hmin = min(hmin, hn);
+    const bool adv = rem2 < 0;
+    s.rem = rem2 & 31;
+    s.w0 = adv ? s.w1 : s.w0;
+    s.w1 = adv ? s.w2 : s.w1;
+    s.next += adv ? 4u : 0u;
+    s.w2 = ring[((s.next - 4u) & RING_MASK) >> 2];
+    s.hist = hn;
+    return r;
+}
+constexpr int SPEC_UNIT = 4;   // steps per speculative unit
 
 // ---- per-row LDS ring ------------------------------------------------------------------------------
 // Tops the ring up with 256-byte chunks while there is room in front of the oldest live dword.
@@ -187,6 +252,7 @@ __device__ __forceinline__ void rice_init(Rice& s, uint32_t& filled, uint32_t st
     s.hist = init_hist;
     s.signmod = 0;
     s.zrun = 0;
+    s.nforce = 0xFFFFFFFFu;
     filled = d & ~(uint32_t)(FILL_CHUNK - 1);
     wave_sync();
     ring_fill<LPS>(ring, filled, s.next, base, limit, l, enable);
@@ -266,6 +332,58 @@ __device__ __forceinline__ int fir_step(Fir<TPL>& f, int err, int i, int N, int 
     f.hist[0] = __builtin_amdgcn_update_dpp(out, f.hist[0], DPP_ROW_SHR1, 0xF, 0xF, false);
     f.prev = out;
     return out;
+}
+
+// ---- FIR fast step --------------------------------------------------------------------------------
+// The steady state of fir_step for one tap register per lane (1 <= N <= 16, i > N), branch-free.
+// NARROW: every operand fits 24 bits (rss <= 17), so the full-rate 24-bit multipliers are exact.
+// NRED:   3 when every row of the wave has N <= 8 (taps live in lanes 0..7 only), else 4.
+// Lanes >= N keep coef == 0 and w == 0.  A row that is switched off is fed err = 0 / coef = 0 and just idles.
+struct FirLane {
+    int hist, coef, base;
+    int q, rnd, rss, qmask;   // row-uniform
+    uint32_t w;               // N - j for tap j < N, else 0
+    int bpaddr;               // ds_bpermute byte address of lane N-1 of this row
+    bool tap;                 // j < N
+};
+
+template <int NRED>
+__device__ __forceinline__ int row_allreduce_n(int v) {
+    v = wadd(v, dpp0<DPP_QUAD_1032>(v));
+    v = wadd(v, dpp0<DPP_QUAD_2301>(v));
+    v = wadd(v, dpp0<DPP_ROW_HALF_MIRROR>(v));
+    if (NRED > 3) v = wadd(v, dpp0<DPP_ROW_MIRROR>(v));
+    return v;
+}
+template <int NRED>
+__device__ __forceinline__ int row_suffix_scan_n(int v) {
+    v = wadd(v, dpp0<DPP_ROW_SHL1>(v));
+    v = wadd(v, dpp0<DPP_ROW_SHL2>(v));
+    v = wadd(v, dpp0<DPP_ROW_SHL4>(v));
+    if (NRED > 3) v = wadd(v, dpp0<DPP_ROW_SHL8>(v));
+    return v;
+}
+
+template <bool NARROW, int NRED>
+__device__ __forceinline__ void fir_fast(FirLane& f, int err) {
+    const int nb = __builtin_amdgcn_ds_bpermute(f.bpaddr, f.hist);   // tap N-1 = next step's base; needed last
+    const int d = wsub(f.hist, f.base);                                       // :303
+    const int p = NARROW ? __mul24(d, f.coef) : wmul(d, f.coef);
+    const int sum = row_allreduce_n<NRED>(p);
+    const int out = __builtin_amdgcn_sbfe(wadd(wadd(wadd(f.rnd, sum) >> f.q, f.base), err), 0, f.rss);  // :306-310
+    // sign-LMS (:312-332), parallel form -- see fir_step for the derivation
+    const int s = err >> 31;
+    const int a = max(d, -d);
+    const uint32_t aq = (uint32_t)(a + (s & f.qmask)) >> f.q;
+    uint32_t cc = NARROW ? __umul24(aq, f.w) : aq * f.w;
+    cc = min(cc, 1u << 26);
+    const uint32_t incl = (uint32_t)row_suffix_scan_n<NRED>((int)cc);
+    const uint32_t E = (uint32_t)((err ^ s) - s);
+    const bool visit = f.tap && (E > incl - cc);
+    const int sd = min(max(d, -1), 1);  // sign(d): v_med3_i32
+    f.coef += visit ? (sd ^ s) - s : 0;
+    f.hist = __builtin_amdgcn_update_dpp(out, f.hist, DPP_ROW_SHR1, 0xF, 0xF, false);
+    f.base = nb;
 }
 
 // Everything a lane knows about its packet / stream after the header parse.

@@ -223,7 +223,8 @@ template <int F>
 struct SplitShared {
     uint32_t rings[4 * F][RING_BYTES / 4];
     int resq[2][CHUNK][4 * F];
-    int dummy[64];
+    int zeros[CHUNK][4 * F];   // residuals of a switched-off row
+    int dummy[CHUNK * 4 * F + 64];
 };
 
 template <typename T>
@@ -235,6 +236,9 @@ __device__ __forceinline__ T wave_max(T v) {
     }
     return v;
 }
+
+// value of `v` in lane `src` (a lane mirrors itself when src == its own id)
+__device__ __forceinline__ int mirror_i(int v, int src) { return __shfl(v, src, 64); }
 
 template <int F>
 __device__ void entropy_wave(const alac_decode_params& p, uint32_t pkt0, int lane, SplitShared<F>& sh, int nchunks) {
@@ -249,7 +253,6 @@ __device__ void entropy_wave(const alac_decode_params& p, uint32_t pkt0, int lan
         if (p.out_bytes) p.out_bytes[pkt] = m.out_bytes;
         if (p.out_samples) p.out_samples[pkt] = m.n;
     }
-    uint32_t* ring = sh.rings[g];
     const bool compressed = valid && m.status == 0 && !m.esc;
     const bool stream_on = compressed && (chan == 0 || m.stereo);
     const int n_row = stream_on ? m.n : 0;
@@ -260,52 +263,150 @@ __device__ void entropy_wave(const alac_decode_params& p, uint32_t pkt0, int lan
     rc.kmask = (1u << cfg.rice_kmodifier) - 1u;
     rc.hist_mult = m.ricemod * (cfg.rice_history_mult / 4);
     rc.rss = m.rss;
+    int init_hist = cfg.rice_initial_history;
 
     Rice rs;
-    rs.w0 = rs.w1 = rs.w2 = 0; rs.rem = 0; rs.next = 12; rs.hist = 0; rs.signmod = 0; rs.zrun = 0;
+    rs.w0 = rs.w1 = rs.w2 = 0; rs.rem = 0; rs.next = 12; rs.hist = 0; rs.signmod = 0; rs.zrun = 0; rs.nforce = 0;
     uint32_t filled = 0;
+    if (p.dbg && lane == 0) p.dbg[8 * blockIdx.x + 0] = clock64();
 
-    // ---- pre-scan of the A streams (see v1) ----
+    // ---- pre-scan: Rice-only pass over the A stream of every stereo packet, to find where B starts ----
+    // Lanes with nothing to scan shadow the first scanning group (same ring, same state), so the whole
+    // wave stays in lock step on the branch-free fast step.
     const bool pre_on = stream_on && chan == 0 && m.stereo;
-    const int n_pre = pre_on ? m.n : 0;
-    const int npre_max = __builtin_amdgcn_readfirstlane(wave_max(n_pre));
     uint32_t bstart = m.ricebit;
-    if (npre_max > 0) {
-        rice_init<LPS>(rs, filled, m.ricebit, cfg.rice_initial_history, ring, m.base, m.limit, sub, pre_on);
-        int dummy = 0;
-        for (int i = 0; i < npre_max; i++) {
-            if (i < n_pre) (void)rice_step(rs, rc, n_pre - 1 - i, i, &dummy, ring);
-            if ((i & 15) == 15) {
+    {
+        const uint64_t onmask = __builtin_amdgcn_ballot_w64(pre_on);
+        if (onmask) {
+            const int src = pre_on ? lane : (int)__builtin_ctzll(onmask);
+            RiceCfg pc;
+            pc.kmod = mirror_i(rc.kmod, src);
+            pc.kmask = (1u << pc.kmod) - 1u;
+            pc.hist_mult = mirror_i(rc.hist_mult, src);
+            pc.rss = mirror_i(rc.rss, src);
+            const int n_eff = mirror_i(m.n, src);
+            const int ih = mirror_i(init_hist, src);
+            const uint32_t sb = (uint32_t)mirror_i((int)m.ricebit, src);
+            const uint32_t* pring = sh.rings[mirror_i(g, src)];
+            const int nmin = __builtin_amdgcn_readfirstlane(-wave_max(-n_eff));
+            const int nmax = __builtin_amdgcn_readfirstlane(wave_max(pre_on ? m.n : 0));
+            rice_init<LPS>(rs, filled, sb, ih, sh.rings[g], m.base, m.limit, sub, pre_on);
+            // the shadows read the donor's ring: reload their window from it
+            if (!pre_on) {
+                const uint32_t d0 = rs.next - 12u;
+                rs.w0 = pring[(d0 & RING_MASK) >> 2];
+                rs.w1 = pring[((d0 + 4u) & RING_MASK) >> 2];
+                rs.w2 = pring[((d0 + 8u) & RING_MASK) >> 2];
+            }
+            int dummy = 0;
+            int i = 0;
+            for (; i + CHUNK <= nmin - 1; i += CHUNK) {   // every lane has a sample left after each of these
+                for (int u = 0; u < CHUNK; u += SPEC_UNIT) {
+                    bool redo = __builtin_amdgcn_ballot_w64(rs.nforce == 0u) != 0;
+                    if (!redo) {
+                        const Rice snap = rs;
+                        uint32_t xmax = 0;
+                        int hmin = 0x7FFFFFFF;
+#pragma unroll
+                        for (int ii = 0; ii < SPEC_UNIT; ii++) (void)rice_spec_step<false>(rs, pc, pring, xmax, hmin);
+                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(xmax > 8u || hmin < 128) != 0, 0)) {
+                            rs = snap;
+                            redo = true;
+                        }
+                    }
+                    if (redo) {
+                        for (int ii = 0; ii < SPEC_UNIT; ii++)
+                            (void)rice_step(rs, pc, n_eff - 1 - (i + u + ii), i + u + ii, &dummy, pring);
+                    }
+                }
                 wave_sync();
-                ring_fill<LPS>(ring, filled, rs.next, m.base, m.limit, sub, pre_on);
+                ring_fill<LPS>(sh.rings[g], filled, rs.next, m.base, m.limit, sub, pre_on);
                 wave_sync();
             }
+            for (; i < nmax; i++) {                        // ragged tail, generic
+                if (pre_on && i < m.n) (void)rice_step(rs, pc, m.n - 1 - i, i, &dummy, pring);
+                if ((i & 15) == 15) {
+                    wave_sync();
+                    ring_fill<LPS>(sh.rings[g], filled, rs.next, m.base, m.limit, sub, pre_on && i + 1 < m.n);
+                    wave_sync();
+                }
+            }
+            bstart = rice_bitpos(rs);
         }
-        bstart = rice_bitpos(rs);
     }
     const uint32_t other = (uint32_t)__shfl((int)bstart, lane ^ LPS, 64);
     const uint32_t startbit = (chan == 1) ? other : m.ricebit;
+    if (p.dbg && lane == 0) p.dbg[8 * blockIdx.x + 1] = clock64();
 
+    // ---- main pass: every stream, one residual per step into the LDS queue ----
+    const uint64_t onmask = __builtin_amdgcn_ballot_w64(stream_on);
+    const int src = (stream_on || !onmask) ? lane : (int)__builtin_ctzll(onmask);
+    RiceCfg mc;
+    mc.kmod = mirror_i(rc.kmod, src);
+    mc.kmask = (1u << mc.kmod) - 1u;
+    mc.hist_mult = mirror_i(rc.hist_mult, src);
+    mc.rss = mirror_i(rc.rss, src);
+    const int n_eff = mirror_i(m.n, src);
+    const int ih = mirror_i(init_hist, src);
+    const uint32_t sb = (uint32_t)mirror_i((int)startbit, src);
+    const uint32_t* mring = sh.rings[mirror_i(g, src)];
+    const int nmin = onmask ? __builtin_amdgcn_readfirstlane(-wave_max(-n_eff)) : 0;
     const int nmax = __builtin_amdgcn_readfirstlane(wave_max(n_row));
-    if (nmax > 0) rice_init<LPS>(rs, filled, startbit, cfg.rice_initial_history, ring, m.base, m.limit, sub, stream_on);
+    if (nmax > 0) {
+        rice_init<LPS>(rs, filled, sb, ih, sh.rings[g], m.base, m.limit, sub, stream_on);
+        if (!stream_on) {
+            const uint32_t d0 = rs.next - 12u;
+            rs.w0 = mring[(d0 & RING_MASK) >> 2];
+            rs.w1 = mring[((d0 + 4u) & RING_MASK) >> 2];
+            rs.w2 = mring[((d0 + 8u) & RING_MASK) >> 2];
+        }
+    }
 
-    // residual queue slot of this stream; lanes other than the group's first write to a dummy word
+    unsigned long long ewait = 0;
     for (int c = 0; c < nchunks; c++) {
         const int i0 = c * CHUNK;
+        // residual queue slot of this stream; lanes other than the group's first write to a dummy word
         int* q = (sub == 0) ? &sh.resq[c & 1][0][g] : &sh.dummy[lane];
-        const int qstride = (sub == 0) ? S : 0;
         if (i0 < nmax) {
-            for (int ii = 0; ii < CHUNK; ii++) {
-                const int i = i0 + ii;
-                int r = 0;
-                if (i < n_row) r = rice_step(rs, rc, n_row - 1 - i, i, &flags, ring);
-                q[ii * qstride] = r;
+            if (i0 + CHUNK <= nmin - 1) {                  // fast chunk: all lanes decode, a sample always remains
+                for (int u = 0; u < CHUNK; u += SPEC_UNIT) {
+                    bool redo = __builtin_amdgcn_ballot_w64(rs.nforce == 0u) != 0;
+                    if (!redo) {
+                        const Rice snap = rs;
+                        uint32_t xmax = 0;
+                        int hmin = 0x7FFFFFFF;
+#pragma unroll
+                        for (int ii = 0; ii < SPEC_UNIT; ii++)
+                            q[(u + ii) * S] = rice_spec_step<true>(rs, mc, mring, xmax, hmin);
+                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(xmax > 8u || hmin < 128) != 0, 0)) {
+                            rs = snap;
+                            redo = true;
+                        }
+                    }
+                    if (redo) {   // some lane met an escape / a zero run: decode this unit with the full step
+                        for (int ii = 0; ii < SPEC_UNIT; ii++)
+                            q[(u + ii) * S] = rice_step(rs, mc, n_eff - 1 - (i0 + u + ii), i0 + u + ii, &flags, mring);
+                    }
+                }
+            } else {                                        // generic chunk (ragged sample counts, last samples)
+                const int qstride = (sub == 0) ? S : 0;
+                for (int ii = 0; ii < CHUNK; ii++) {
+                    const int i = i0 + ii;
+                    int r = 0;
+                    if (i < n_row) r = rice_step(rs, mc, n_row - 1 - i, i, &flags, mring);
+                    q[ii * qstride] = r;
+                }
             }
             wave_sync();
-            ring_fill<LPS>(ring, filled, rs.next, m.base, m.limit, sub, stream_on && i0 + CHUNK < n_row);
+            ring_fill<LPS>(sh.rings[g], filled, rs.next, m.base, m.limit, sub, stream_on && i0 + CHUNK < n_row);
         }
+        const unsigned long long tb = p.dbg ? clock64() : 0;
         wg_sync();  // chunk c is ready for the reconstruction waves
+        if (p.dbg) ewait += clock64() - tb;
     }
+    if (p.dbg && lane == 0) p.dbg[8 * blockIdx.x + 5] = p.dbg[8 * blockIdx.x + 0] + ewait;
+    if (!stream_on) flags = 0;  // shadows decode somebody else's stream
+    if (p.dbg && lane == 0) p.dbg[8 * blockIdx.x + 2] = clock64();
 
     // ---- status, in the reference's control-flow order (same as v1 / the oracle) ----
     const int fl_other = __shfl(flags, lane ^ LPS, 64);
@@ -336,6 +437,48 @@ __device__ void entropy_wave(const alac_decode_params& p, uint32_t pkt0, int lan
     }
 }
 
+// Output stage of a reconstruction wave: un-mix + shift bytes + coalesced int32 store of the (up to) 16
+// sample frames of chunk i0.  `newest` is hist[0]: lane j holds out[last - j].
+__device__ __forceinline__ void recon_output(const alac_decode_params& p, const Meta& m, int newest, int i0, int n_out,
+                                             int lane, int chan, int32_t* pcm_slot) {
+    const int l = lane & 15;
+    const int cnt = min(CHUNK, n_out - i0);   // frames of this packet in this chunk (<= 0: none)
+    const bool live = l < cnt;
+    const int i = m.esc ? i0 + l : i0 + cnt - 1 - l;
+    int mine = newest;
+    if (live && m.esc && (chan == 0 || m.stereo)) {  // raw samples (:500-525 / :665-699)
+        const uint32_t bp = m.rawbit + (uint32_t)((i * (m.stereo ? 2 : 1) + chan) * m.ss);
+        mine = __builtin_amdgcn_sbfe((int)peek_bits(m.base, m.limit, bp, m.ss), 0, m.ss);
+    }
+    const int partner = __shfl(mine, lane ^ 16, 64);
+    if (live) {
+        const int a = chan == 0 ? mine : partner, b = chan == 0 ? partner : mine;
+        int val;
+        if (m.stereo) {
+            int left, right;
+            if (m.mixweight != 0) {                                     // :344-351
+                right = wsub(a, wmul(b, m.mixweight) >> (m.mixshift & 31));
+                left = wadd(right, b);
+            } else {
+                left = a;
+                right = b;
+            }
+            val = chan == 0 ? left : right;
+        } else {
+            val = chan == 0 ? a : 0;                                     // :531-541: silent second channel
+        }
+        if (m.ss == 24) {
+            if (m.ub != 0 && !m.esc && (chan == 0 || m.stereo)) {       // :381-388 / :549-554
+                const uint32_t bp = m.ubit + (uint32_t)((i * (m.stereo ? 2 : 1) + chan) * 8 * m.ub);
+                const uint32_t sb = peek_bits(m.base, m.limit, bp, 8 * m.ub);
+                val = (int)(((uint32_t)val << (8 * m.ub)) | sb);
+            }
+            val = __builtin_amdgcn_sbfe(val, 0, 24);
+        }
+        if (chan < m.nc) pcm_slot[(int64_t)i * m.nc + chan] = val;
+    }
+}
+
 template <int F, int TPL>
 __device__ void recon_wave_impl(const alac_decode_params& p, const Meta& m, bool valid, int g, int lane,
                                 SplitShared<F>& sh, int nchunks, uint32_t pkt) {
@@ -361,55 +504,70 @@ __device__ void recon_wave_impl(const alac_decode_params& p, const Meta& m, bool
     f.prev = 0;
     const int nmax = __builtin_amdgcn_readfirstlane(wave_max(n_row));
 
+    // ---- fast-path eligibility (wave-uniform) ----
+    // every switched-on row in the general predictor mode with one tap register: 1 <= N <= 16
+    const bool row_ok = !stream_on || (m.N >= 1 && m.N <= 16);
+    const bool can_fast = TPL == 1 && !__builtin_amdgcn_ballot_w64(!row_ok) && nmax > 0;
+    const int Nw = __builtin_amdgcn_readfirstlane(wave_max(stream_on ? m.N : 0));
+    const int nmin = __builtin_amdgcn_readfirstlane(-wave_max(stream_on ? -m.n : -0x7FFFFFFF));
+    const bool narrow = !__builtin_amdgcn_ballot_w64(stream_on && m.rss > 17);
+
+    FirLane fl;
+    fl.q = stream_on ? m.q : 1;
+    fl.rnd = stream_on ? m.rnd : 0;
+    fl.rss = stream_on ? m.rss : 16;
+    fl.qmask = (1 << fl.q) - 1;
+    fl.tap = stream_on && l < m.N;
+    fl.w = fl.tap ? (uint32_t)(m.N - l) : 0u;
+    fl.bpaddr = (rowlane0 + (stream_on ? (m.N - 1) & 15 : 0)) * 4;
+    const int* qzero = &sh.zeros[0][g];
+
+    unsigned long long rwait = 0;
     for (int c = 0; c < nchunks; c++) {
         const int i0 = c * CHUNK;
+        const unsigned long long tb = (p.dbg && c > 0) ? clock64() : 0;
         wg_sync();  // wait for chunk c
+        if (p.dbg && c > 0) rwait += clock64() - tb;
+        if (p.dbg && c == 0 && lane == 0 && g == 0) p.dbg[8 * blockIdx.x + 3] = clock64();
         if (i0 < nmax) {
             const int* q = &sh.resq[c & 1][0][g];
-            for (int ii = 0; ii < CHUNK; ii++) {
-                const int i = i0 + ii;
-                if (i < n_row) {
-                    const int err = q[ii * S];
-                    (void)fir_step<TPL>(f, err, i, m.N, m.q, m.rnd, m.rss, l, rowlane0);
-                }
-            }
-        }
-        // ---- output stage.  After the chunk, hist[0] lane j holds out[last - j]. ----
-        const int cnt = min(CHUNK, n_out - i0);   // frames of this packet in this chunk (<= 0: none)
-        const bool live = l < cnt;
-        const int i = m.esc ? i0 + l : i0 + cnt - 1 - l;
-        int mine = f.hist[0];
-        if (live && m.esc && (chan == 0 || m.stereo)) {
-            const uint32_t bp = m.rawbit + (uint32_t)((i * (m.stereo ? 2 : 1) + chan) * m.ss);
-            mine = __builtin_amdgcn_sbfe((int)peek_bits(m.base, m.limit, bp, m.ss), 0, m.ss);
-        }
-        const int partner = __shfl(mine, lane ^ 16, 64);
-        if (live) {
-            const int a = chan == 0 ? mine : partner, b = chan == 0 ? partner : mine;
-            int val;
-            if (m.stereo) {
-                int left, right;
-                if (m.mixweight != 0) {
-                    right = wsub(a, wmul(b, m.mixweight) >> (m.mixshift & 31));
-                    left = wadd(right, b);
+            if (TPL == 1 && can_fast && i0 > Nw && i0 + CHUNK <= nmin) {
+                fl.hist = f.hist[0];
+                fl.coef = f.coef[0];
+                fl.base = f.base;
+                const int* qf = stream_on ? q : qzero;
+                int err = qf[0];
+#define ALAC_FAST_CHUNK(NARROW_, NRED_)                                   \
+    _Pragma("unroll") for (int ii = 0; ii < CHUNK; ii++) {                \
+        const int en = qf[(ii + 1 < CHUNK ? ii + 1 : ii) * S];            \
+        fir_fast<NARROW_, NRED_>(fl, err);                                \
+        err = en;                                                         \
+    }
+                if (narrow) {
+                    if (Nw <= 8) { ALAC_FAST_CHUNK(true, 3) } else { ALAC_FAST_CHUNK(true, 4) }
                 } else {
-                    left = a;
-                    right = b;
+                    if (Nw <= 8) { ALAC_FAST_CHUNK(false, 3) } else { ALAC_FAST_CHUNK(false, 4) }
                 }
-                val = chan == 0 ? left : right;
+#undef ALAC_FAST_CHUNK
+                f.hist[0] = fl.hist;
+                f.coef[0] = fl.coef;
+                f.base = fl.base;
+                f.prev = __shfl(fl.hist, rowlane0, 64);
             } else {
-                val = chan == 0 ? a : 0;
-            }
-            if (m.ss == 24) {
-                if (m.ub != 0 && !m.esc && (chan == 0 || m.stereo)) {
-                    const uint32_t bp = m.ubit + (uint32_t)((i * (m.stereo ? 2 : 1) + chan) * 8 * m.ub);
-                    const uint32_t sb = peek_bits(m.base, m.limit, bp, 8 * m.ub);
-                    val = (int)(((uint32_t)val << (8 * m.ub)) | sb);
+                for (int ii = 0; ii < CHUNK; ii++) {
+                    const int i = i0 + ii;
+                    if (i < n_row) {
+                        const int err = q[ii * S];
+                        (void)fir_step<TPL>(f, err, i, m.N, m.q, m.rnd, m.rss, l, rowlane0);
+                    }
                 }
-                val = __builtin_amdgcn_sbfe(val, 0, 24);
             }
-            if (chan < m.nc) pcm_slot[(int64_t)i * m.nc + chan] = val;
         }
+        recon_output(p, m, f.hist[0], i0, n_out, lane, chan, pcm_slot);
+    }
+    if (p.dbg && lane == 0 && g == 0) {
+        p.dbg[8 * blockIdx.x + 4] = clock64();
+        p.dbg[8 * blockIdx.x + 6] = p.dbg[8 * blockIdx.x + 0] + rwait;
     }
 }
 
@@ -445,6 +603,8 @@ __device__ __forceinline__ void split_kernel_body(const alac_decode_params& p) {
     }
     const int nall = __builtin_amdgcn_readfirstlane(wave_max(n_any));
     const int nchunks = (nall + CHUNK - 1) / CHUNK;
+    for (int t = threadIdx.x; t < CHUNK * 4 * F; t += blockDim.x) (&sh.zeros[0][0])[t] = 0;
+    wg_sync();
     if (wave == 0) entropy_wave<F>(p, pkt0, lane, sh, nchunks);
     else recon_wave<F>(p, pkt0, wave - 1, lane, sh, nchunks);
 }

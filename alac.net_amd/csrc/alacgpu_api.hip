@@ -201,6 +201,24 @@ int alacgpu_decode_batch_device(alacgpu_ctx* ctx, const void* d_blob, uint64_t b
     p.out_bytes = (int32_t*)d_out_bytes;
     p.out_samples = (int32_t*)d_out_samples;
     p.status = (int32_t*)d_status;
+    p.dbg = nullptr;
+    if (std::getenv("ALACGPU_DEBUG_STAMPS")) {  // diagnostic: per-WG phase stamps, printed to stderr (blocks)
+        const uint32_t nwg = (n_packets + 1) / 2;
+        unsigned long long* d = nullptr;
+        HIP_TRY(ctx, hipMalloc((void**)&d, sizeof(unsigned long long) * 8 * nwg));
+        HIP_TRY(ctx, hipMemset(d, 0, sizeof(unsigned long long) * 8 * nwg));
+        p.dbg = d;
+        int rc = launch(ctx, p, (hipStream_t)hip_stream);
+        HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)hip_stream));
+        unsigned long long* h = (unsigned long long*)std::malloc(sizeof(unsigned long long) * 8 * nwg);
+        HIP_TRY(ctx, hipMemcpy(h, d, sizeof(unsigned long long) * 8 * nwg, hipMemcpyDeviceToHost));
+        double acc[8] = {0}; uint32_t cnt = 0;
+        for (uint32_t w = 0; w < nwg; w++) { if (!h[8 * w]) continue; cnt++; for (int j = 1; j < 8; j++) acc[j] += (double)(h[8 * w + j] - h[8 * w]); }
+        if (cnt) std::fprintf(stderr, "[alacgpu stamps] wgs=%u  prescan_end=%.0f  entropy_end=%.0f  recon_first_chunk=%.0f  recon_end=%.0f  entropy_barrier_wait=%.0f  recon_barrier_wait=%.0f (cycles from WG start)\n",
+                              cnt, acc[1] / cnt, acc[2] / cnt, acc[3] / cnt, acc[4] / cnt, acc[5] / cnt, acc[6] / cnt);
+        std::free(h); (void)hipFree(d);
+        return rc;
+    }
     return launch(ctx, p, (hipStream_t)hip_stream);
 }
 
