@@ -1,0 +1,64 @@
+"""N>1 path on CPU: world_size-2 gloo processes shard a batch by packet range, decode their shard
+(the CPU oracle stands in for the GPU decode here: this test is about the partitioning + the PCM
+all-gather, which is backend-agnostic), all-gather the PCM and compare with the single-rank result."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, n_packets, outdir):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from alac.net_amd import sharding, synth
+    import alac_oracle_py as orc
+
+    b = synth.make_config_batch(5, n_packets=n_packets, n_threads=1)  # identical on every rank (seeded)
+    blob, offs, sizes, ci, (lo, hi) = sharding.shard_batch(b["blob"], b["offsets"], b["sizes"], b["cfg_idx"], rank, world)
+    pcm, ob, os_, st = orc.decode_batch(orc.make_cfgs(b["stream_cfgs"]), blob, offs, sizes, ci, b["slot_ints"])
+    per = sharding.padded_shard(n_packets, world)
+    local = torch.zeros((per, b["slot_ints"]), dtype=torch.int32)
+    local[: hi - lo] = torch.from_numpy(pcm)
+    full = sharding.allgather_pcm(local, n_packets)
+    assert full.shape == (n_packets, b["slot_ints"])
+    if rank == 0:
+        ref = orc.decode_batch(orc.make_cfgs(b["stream_cfgs"]), b["blob"], b["offsets"], b["sizes"], b["cfg_idx"],
+                               b["slot_ints"])[0]
+        ok = bool(np.array_equal(full.numpy(), ref))
+        open(os.path.join(outdir, "result.txt"), "w").write("ok" if ok else "mismatch")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_packets", [10, 7])  # 7: uneven shards, exercises the padding
+def test_two_rank_shard_and_allgather(tmp_path, n_packets):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), n_packets, str(tmp_path)), nprocs=world, join=True)
+    assert open(tmp_path / "result.txt").read() == "ok"
+
+
+def test_shard_ranges_cover_everything():
+    from alac.net_amd import sharding
+
+    for n in (0, 1, 7, 4096, 65536):
+        for w in (1, 2, 4, 8):
+            r = [sharding.shard_range(n, k, w) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(r[k][1] == r[k + 1][0] for k in range(w - 1))
+            assert max(h - l for l, h in r) - min(h - l for l, h in r) <= 1

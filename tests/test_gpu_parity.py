@@ -125,3 +125,119 @@ def test_statuses(pkg, oracle, synth, variant):
     g, o = run_both(pkg, oracle, b, variant=variant)
     assert o[3].tolist() == [1, 3, 0, 0, 0, 5]
     assert_same(g, o, b["stream_cfgs"], None)
+
+
+def _random_recipe_batch(synth, seed, count, stereo, is24):
+    rng = np.random.default_rng(seed)
+    d = synth.packet_descs(count, max_samples_per_frame=4096, sample_size=24 if is24 else 16, stereo=int(stereo))
+    d["n"] = rng.integers(1, 900, count)
+    d["n"][:4] = [1, 2, 33, 4096]
+    d["pred_order"] = rng.integers(0, 32, (count, 2))
+    d["quant"] = rng.integers(0, 16, (count, 2))
+    d["ricemod"] = rng.integers(0, 8, (count, 2))
+    d["mix_shift"] = rng.integers(0, 9, count)
+    d["mix_weight"] = np.minimum(rng.integers(0, 256, count), 1 << d["mix_shift"].astype(np.int64))
+    d["ub"] = rng.integers(0, 3 if is24 else 1, count)
+    rc = rng.random(count) < 0.5
+    d["coef_mode"] = np.where(rc, 1, 0)
+    d["coefs"] = rng.integers(-3000, 3000, (count, 2, 32))
+    d["escape"] = rng.random(count) < 0.05
+    return d
+
+
+@pytest.mark.parametrize("variant", [1, 3, 4])
+@pytest.mark.parametrize("stereo,is24,loud", [(True, False, False), (True, True, True), (False, False, True), (False, True, False)])
+def test_random_recipes_vs_oracle(pkg, oracle, synth, variant, stereo, is24, loud):
+    d = _random_recipe_batch(synth, 1234 + 2 * stereo + is24, 96, stereo, is24)
+    sig = synth.default_signal(77)
+    sig["silence_prob"] = 0.3
+    if loud:
+        sig["amp_lo_log2"], sig["amp_hi_log2"], sig["noise_sigma"] = 14.5, 15.0, 9000.0
+    b = synth.make_batch(d, sig, want_pcm=True)
+    b.update(stream_cfgs=[(4096, 24 if is24 else 16, 40, 10, 14, 2 if stereo else 1)], cfg_idx=None)
+    g, o = run_both(pkg, oracle, b, variant=variant)
+    assert (o[3] == 0).all()
+    assert_same(g, o, b["stream_cfgs"], None)
+    for p in range(len(d)):
+        cnt = int(d["n"][p]) * (2 if stereo else 1)
+        assert np.array_equal(g[0][p, :cnt], b["pcm"][p, :cnt])
+
+
+@pytest.mark.parametrize("variant", [1, 3])
+def test_exotic_stream_configs(pkg, oracle, synth, variant):
+    # other rice parameters than the usual 40/10/14, several stream configs in one batch
+    cfgs = [(4096, 16, 40, 10, 14, 2), (4096, 16, 255, 255, 16, 2), (4096, 16, 8, 0, 1, 2), (4096, 24, 100, 3, 9, 2)]
+    d = synth.packet_descs(64, n=700, max_samples_per_frame=4096)
+    ci = (np.arange(64) % 4).astype(np.uint16)
+    for j, c in enumerate(cfgs):
+        m = ci == j
+        d["sample_size"][m] = c[1]
+        d["rice_history_mult"][m], d["rice_initial_history"][m], d["rice_kmodifier"][m] = c[2], c[3], c[4]
+    d["pred_order"] = np.random.default_rng(5).integers(0, 32, (64, 2))
+    b = synth.make_batch(d, synth.default_signal(5), want_pcm=True)
+    b.update(stream_cfgs=cfgs, cfg_idx=ci)
+    g, o = run_both(pkg, oracle, b, variant=variant)
+    assert (o[3] == 0).all()
+    assert_same(g, o, cfgs, ci)
+
+
+@pytest.mark.parametrize("variant", [1, 3])
+def test_mutated_packets_never_hang_and_match(pkg, oracle, synth, variant):
+    # flip bits in valid packets; every packet is followed by zero padding so that both decoders see
+    # zeros past a (possibly now too short) packet.  The kernel must terminate and agree with the oracle
+    # on status; where both say OK the PCM must agree too.
+    rng = np.random.default_rng(4321)
+    src = synth.make_config_batch(5, n_packets=160, seed=99)
+    blob = bytearray()
+    offs, sizes = [], []
+    for p in range(160):
+        o, s = int(src["offsets"][p]), int(src["sizes"][p])
+        pkt = bytearray(bytes(src["blob"][o:o + s]))
+        for _ in range(int(rng.integers(1, 6))):
+            pos = int(rng.integers(3, len(pkt))) if rng.random() < 0.8 else int(rng.integers(0, min(12, len(pkt))))
+            pkt[pos] ^= 1 << int(rng.integers(0, 8))
+        if rng.random() < 0.2:
+            pkt = pkt[: int(rng.integers(4, len(pkt)))]
+        offs.append(len(blob))
+        sizes.append(len(pkt))
+        blob += pkt + bytes(96 * 1024)  # far more zeros than any decoder can run through
+    b = dict(src)
+    b["blob"] = np.frombuffer(bytes(blob), dtype=np.uint8)
+    b["offsets"] = np.array(offs, dtype=np.uint64)
+    b["sizes"] = np.array(sizes, dtype=np.uint32)
+    g, o = run_both(pkg, oracle, b, variant=variant)
+    assert set(np.unique(o[3])) - {0}, "the mutation should break at least some packets"
+    assert_same(g, o, b["stream_cfgs"], b["cfg_idx"])
+
+
+def test_full_size_cfg2_roundtrip_property(pkg, synth):
+    # BASELINE configs[1] at full size (4096 packets x 4096 stereo samples): size-independent property
+    # decode(encode(pcm)) == pcm, checked without the oracle (which would take minutes single-threaded).
+    b = synth.make_config_batch(2, want_pcm=True)
+    with pkg.AlacGpuContext(b["stream_cfgs"]) as ctx:
+        pcm, ob, os_, st = ctx.decode_batch(b["blob"], b["offsets"], b["sizes"], None, b["slot_ints"])
+    assert (st == 0).all() and (os_ == 4096).all() and (ob == 16384).all()
+    assert np.array_equal(pcm, b["pcm"])
+
+
+def test_alacfile_mirror_decode_frame(pkg, oracle, synth):
+    # the reference's own call sequence: new AlacFile(samplesize, numchannels); SetInfo(codecData); DecodeFrame(in, out)
+    cd = [0] * 24 + [0, 0, 0x10, 0x00, 0, 24, 40, 10, 14, 2, 0, 255, 0, 0, 0x20, 0xE7, 0, 6, 0x9F, 0xE4, 0, 0, 0xAC, 0x44]
+    d = synth.packet_descs(1, n=4096, sample_size=24, ub=1, pred_order=16)
+    b = synth.make_batch(d, synth.default_signal(3), want_pcm=True)
+    pkt = bytes(b["blob"][: int(b["sizes"][0])])
+    f = pkg.AlacFile(24, 2)
+    f.SetInfo(cd)
+    out = np.zeros(1024 * 80, dtype=np.int32)   # AlacContext.cs:65
+    nbytes = f.DecodeFrame(pkt, out)
+    assert nbytes == 4096 * 3 * 2
+    cfg = (4096, 24, 40, 10, 14, 2)
+    st_, opcm, ob, n = oracle.decode_frame(cfg, pkt)
+    ref = oracle.expand_reference_layout(cfg, opcm, n)
+    assert np.array_equal(out[: len(ref)], ref)
+    # and FormatSamples gives back the source PCM bytes (little-endian 24-bit)
+    got = pkg.format_samples(3, out, nbytes)
+    src = b["pcm"][0].astype(np.int32)
+    exp = np.stack([src & 0xFF, (src >> 8) & 0xFF, (src >> 16) & 0xFF], axis=1).astype(np.uint8).reshape(-1)
+    assert np.array_equal(got, exp)
+    f.Dispose()
