@@ -1,0 +1,44 @@
+// P/Invoke binding of include/alacgpu.h for the C# host (drop into ALACDecoder/).
+// NOT compiled or executed in this repository's pipeline: the build image has no .NET toolchain.
+// It is kept mechanical -- blittable arguments only -- and mirrors the executed ctypes binding in
+// alac.net_amd/__init__.py one to one.
+using System;
+using System.Runtime.InteropServices;
+
+namespace ALACdotNET.Decoder
+{
+    [StructLayout(LayoutKind.Sequential, Pack = 1, Size = 12)]
+    internal struct AlacGpuCfg
+    {
+        public uint MaxSamplesPerFrame;   // CodecData[24..27]
+        public byte SampleSize;           // CodecData[29]
+        public byte RiceHistoryMult;      // CodecData[30]
+        public byte RiceInitialHistory;   // CodecData[31]
+        public byte RiceKModifier;        // CodecData[32]
+        public byte NumChannels;          // AlacFile ctor arg
+        public byte CtorSampleSize;       // AlacFile ctor arg
+        public byte Reserved;
+    }
+
+    internal static class AlacGpuNative
+    {
+        private const string Lib = "alacgpu";   // libalacgpu.so
+
+        public const int StOk = 0, StUnsupportedElement = 1, StUnsupportedSampleSize = 2, StUnsupportedPredType = 3,
+                         StBadSampleCount = 4, StOverrun = 5, StRefThrows = 6, StUnsupportedParams = 7;
+
+        [DllImport(Lib)] public static extern int alacgpu_version();
+        [DllImport(Lib)] public static extern int alacgpu_create([In] AlacGpuCfg[] cfgs, uint nCfgs, int device, out IntPtr ctx);
+        [DllImport(Lib)] public static extern void alacgpu_destroy(IntPtr ctx);
+        [DllImport(Lib)] public static extern int alacgpu_cfg_from_codec_data([In] int[] codecData, uint nInts, int samplesize, int numchannels, out AlacGpuCfg cfg);
+        [DllImport(Lib)] public static extern int alacgpu_decode_batch(IntPtr ctx, [In] byte[] blob, ulong blobBytes,
+            [In] ulong[] offsets, [In] uint[] sizes, [In] ushort[] cfgIdx, uint nPackets,
+            [Out] int[] pcmOut, uint slotInts, [Out] int[] outBytes, [Out] int[] outSamples, [Out] int[] status);
+        [DllImport(Lib)] public static extern int alacgpu_decode_frame(IntPtr ctx, uint cfgIndex, [In] byte[] inbuffer, uint inBytes,
+            [Out] int[] outbuffer, uint outCapacityInts, out int outBytes, out int status);
+        [DllImport(Lib)] public static extern IntPtr alacgpu_strerror(int rc);
+        [DllImport(Lib)] public static extern IntPtr alacgpu_last_error(IntPtr ctx);
+
+        public static string Error(int rc) => Marshal.PtrToStringAnsi(alacgpu_strerror(rc));
+    }
+}

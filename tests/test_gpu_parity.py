@@ -241,3 +241,29 @@ def test_alacfile_mirror_decode_frame(pkg, oracle, synth):
     exp = np.stack([src & 0xFF, (src >> 8) & 0xFF, (src >> 16) & 0xFF], axis=1).astype(np.uint8).reshape(-1)
     assert np.array_equal(got, exp)
     f.Dispose()
+
+
+def test_cpp_host_mirror(pkg, oracle, synth, tmp_path):
+    # alac.net_amd/host/AlacFile.hpp: the C++ mirror of AlacFile (ctor / SetInfo / DecodeFrame) over the C ABI
+    import os
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(pkg.__file__), "host", "alacfile_selftest")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    d = synth.packet_descs(1, n=4096, sample_size=24, ub=1, pred_order=16)
+    b = synth.make_batch(d, synth.default_signal(9))
+    pkt = bytes(b["blob"][: int(b["sizes"][0])])
+    path = tmp_path / "packet.bin"
+    path.write_bytes(pkt)
+    out = subprocess.run([exe, str(path), "24", "2"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    cfg = (4096, 24, 40, 10, 14, 2)
+    st_, opcm, ob, n = oracle.decode_frame(cfg, pkt)
+    ref = oracle.expand_reference_layout(cfg, opcm, n)
+    h = 1469598103934665603
+    for x in ref.astype(np.uint32).tolist():
+        h = ((h ^ x) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    assert out.stdout.strip() == f"bytes={ob} ints={len(ref)} fnv={h}", out.stdout
+    # error behaviour: sample size 20 -> the reference's exception text
+    out = subprocess.run([exe, str(path), "20", "2"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 1 and "FIXME: unimplemented sample size 20" in out.stdout
