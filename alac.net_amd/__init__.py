@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIBPATH = os.path.join(_HERE, "csrc", "libalacgpu.so")
+_LIBPATH = os.environ.get("ALACGPU_LIB", os.path.join(_HERE, "csrc", "libalacgpu.so"))  # override: A/B builds only
 _LIB = None
 
 # per-packet status codes (include/alacgpu.h)

@@ -344,7 +344,7 @@ struct FirLane {
     int q, rnd, rss, qmask;   // row-uniform
     uint32_t w;               // N - j for tap j < N, else 0
     int bpaddr;               // ds_bpermute byte address of lane N-1 of this row
-    bool tap;                 // j < N
+    int tlo, thi;             // -1 / +1 on tap lanes (j < N), 0 / 0 elsewhere: bounds of the sign() median
 };
 
 template <int NRED>
@@ -378,10 +378,11 @@ __device__ __forceinline__ void fir_fast(FirLane& f, int err) {
     uint32_t cc = NARROW ? __umul24(aq, f.w) : aq * f.w;
     cc = min(cc, 1u << 26);
     const uint32_t incl = (uint32_t)row_suffix_scan_n<NRED>((int)cc);
-    const uint32_t E = (uint32_t)((err ^ s) - s);
-    const bool visit = f.tap && (E > incl - cc);
-    const int sd = min(max(d, -1), 1);  // sign(d): v_med3_i32
-    f.coef += visit ? (sd ^ s) - s : 0;
+    const uint32_t Ecc = (uint32_t)((err ^ s) - s) + cc;      // |err| + own decrement: visit iff |err| > incl - cc
+    // sign(d) for tap lanes, 0 elsewhere (tlo/thi are -1/+1 on tap lanes and 0/0 on the others)
+    int sd;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(sd) : "v"(d), "v"(f.tlo), "v"(f.thi));
+    f.coef += (Ecc > incl) ? (sd ^ s) - s : 0;
     f.hist = __builtin_amdgcn_update_dpp(out, f.hist, DPP_ROW_SHR1, 0xF, 0xF, false);
     f.base = nb;
 }

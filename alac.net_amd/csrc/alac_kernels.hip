@@ -363,6 +363,7 @@ __device__ void entropy_wave(const alac_decode_params& p, uint32_t pkt0, int lan
     }
 
     unsigned long long ewait = 0;
+    int nredo = 0;
     for (int c = 0; c < nchunks; c++) {
         const int i0 = c * CHUNK;
         // residual queue slot of this stream; lanes other than the group's first write to a dummy word
@@ -383,6 +384,7 @@ __device__ void entropy_wave(const alac_decode_params& p, uint32_t pkt0, int lan
                             redo = true;
                         }
                     }
+                    if (redo) nredo++;
                     if (redo) {   // some lane met an escape / a zero run: decode this unit with the full step
                         for (int ii = 0; ii < SPEC_UNIT; ii++)
                             q[(u + ii) * S] = rice_step(rs, mc, n_eff - 1 - (i0 + u + ii), i0 + u + ii, &flags, mring);
@@ -404,7 +406,10 @@ __device__ void entropy_wave(const alac_decode_params& p, uint32_t pkt0, int lan
         wg_sync();  // chunk c is ready for the reconstruction waves
         if (p.dbg) ewait += clock64() - tb;
     }
-    if (p.dbg && lane == 0) p.dbg[8 * blockIdx.x + 5] = p.dbg[8 * blockIdx.x + 0] + ewait;
+    if (p.dbg && lane == 0) {
+        p.dbg[8 * blockIdx.x + 5] = p.dbg[8 * blockIdx.x + 0] + ewait;
+        p.dbg[8 * blockIdx.x + 7] = p.dbg[8 * blockIdx.x + 0] + (unsigned long long)nredo;
+    }
     if (!stream_on) flags = 0;  // shadows decode somebody else's stream
     if (p.dbg && lane == 0) p.dbg[8 * blockIdx.x + 2] = clock64();
 
@@ -517,8 +522,10 @@ __device__ void recon_wave_impl(const alac_decode_params& p, const Meta& m, bool
     fl.rnd = stream_on ? m.rnd : 0;
     fl.rss = stream_on ? m.rss : 16;
     fl.qmask = (1 << fl.q) - 1;
-    fl.tap = stream_on && l < m.N;
-    fl.w = fl.tap ? (uint32_t)(m.N - l) : 0u;
+    const bool tap = stream_on && l < m.N;
+    fl.tlo = tap ? -1 : 0;
+    fl.thi = tap ? 1 : 0;
+    fl.w = tap ? (uint32_t)(m.N - l) : 0u;
     fl.bpaddr = (rowlane0 + (stream_on ? (m.N - 1) & 15 : 0)) * 4;
     const int* qzero = &sh.zeros[0][g];
 
@@ -605,8 +612,14 @@ __device__ __forceinline__ void split_kernel_body(const alac_decode_params& p) {
     const int nchunks = (nall + CHUNK - 1) / CHUNK;
     for (int t = threadIdx.x; t < CHUNK * 4 * F; t += blockDim.x) (&sh.zeros[0][0])[t] = 0;
     wg_sync();
-    if (wave == 0) entropy_wave<F>(p, pkt0, lane, sh, nchunks);
-    else recon_wave<F>(p, pkt0, wave - 1, lane, sh, nchunks);
+    if (wave == 0) {
+        // the entropy wave is the longest dependent chain of the workgroup: let it win issue arbitration
+        __builtin_amdgcn_s_setprio(3);
+        entropy_wave<F>(p, pkt0, lane, sh, nchunks);
+    }
+    else {
+        recon_wave<F>(p, pkt0, wave - 1, lane, sh, nchunks);
+    }
 }
 
 }  // namespace

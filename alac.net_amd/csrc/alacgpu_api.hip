@@ -214,8 +214,8 @@ int alacgpu_decode_batch_device(alacgpu_ctx* ctx, const void* d_blob, uint64_t b
         HIP_TRY(ctx, hipMemcpy(h, d, sizeof(unsigned long long) * 8 * nwg, hipMemcpyDeviceToHost));
         double acc[8] = {0}; uint32_t cnt = 0;
         for (uint32_t w = 0; w < nwg; w++) { if (!h[8 * w]) continue; cnt++; for (int j = 1; j < 8; j++) acc[j] += (double)(h[8 * w + j] - h[8 * w]); }
-        if (cnt) std::fprintf(stderr, "[alacgpu stamps] wgs=%u  prescan_end=%.0f  entropy_end=%.0f  recon_first_chunk=%.0f  recon_end=%.0f  entropy_barrier_wait=%.0f  recon_barrier_wait=%.0f (cycles from WG start)\n",
-                              cnt, acc[1] / cnt, acc[2] / cnt, acc[3] / cnt, acc[4] / cnt, acc[5] / cnt, acc[6] / cnt);
+        if (cnt) std::fprintf(stderr, "[alacgpu stamps] wgs=%u  prescan_end=%.0f  entropy_end=%.0f  recon_first_chunk=%.0f  recon_end=%.0f  entropy_barrier_wait=%.0f  recon_barrier_wait=%.0f (cycles from WG start)  main_units_redone=%.1f per WG\n",
+                              cnt, acc[1] / cnt, acc[2] / cnt, acc[3] / cnt, acc[4] / cnt, acc[5] / cnt, acc[6] / cnt, acc[7] / cnt);
         std::free(h); (void)hipFree(d);
         return rc;
     }
