@@ -218,6 +218,40 @@ __device__ __forceinline__ int rice_spec_step(Rice& s, const RiceCfg& c, const u
     s.hist = hn;
     return r;
 }
+// Same, for units in which some lane starts inside a zero run or with signModifier pending (digital
+// silence): such a lane emits 0 without touching the bitstream while zrun > 0, and adds signModifier to
+// its next value.  Still straight-line; only a NEW run symbol (history < 128 after a value) or an escape
+// code sends the unit to rice_step.
+template <bool WANT_R>
+__device__ __forceinline__ int rice_spec_step_z(Rice& s, const RiceCfg& c, const uint32_t* ring, uint32_t& xmax,
+                                                int& hmin) {
+    const bool inrun = s.zrun > 0;
+    const uint32_t win = rice_window(s);
+    const uint32_t x = (uint32_t)__builtin_clz(~win | 0x00400000u);
+    xmax = max(xmax, inrun ? 0u : x);
+    const int k = min(22 - __builtin_clz((uint32_t)(s.hist + 1536)), c.kmod);
+    const uint32_t e = __builtin_amdgcn_ubfe(win, (uint32_t)(31 - k) - x, (uint32_t)k);
+    const uint32_t m = __builtin_amdgcn_ubfe(0xFFFFFFFFu, 0u, (uint32_t)k);
+    const uint32_t v = __umul24(x, m) + (e > 1u ? e - 1u : 0u) + (uint32_t)s.signmod;   // :224
+    const int rem2 = inrun ? s.rem : s.rem - (int)(x + (uint32_t)k) - (e > 1u ? 1 : 0);
+    int r = 0;
+    if (WANT_R) r = inrun ? 0 : (int)(v >> 1) ^ -(int)(v & 1u);
+    const int h = s.hist;
+    int hx = (int)(__umul24(v, (uint32_t)c.hist_mult) + (uint32_t)h) - (wmul(h, c.hist_mult) >> 9);
+    asm volatile("" : "+v"(hx));
+    const int hv = (int)v > 0xFFFF ? 0xFFFF : hx;
+    hmin = min(hmin, inrun ? 0x7FFFFFFF : hv);
+    const bool adv = rem2 < 0;
+    s.rem = rem2 & 31;
+    s.w0 = adv ? s.w1 : s.w0;
+    s.w1 = adv ? s.w2 : s.w1;
+    s.next += adv ? 4u : 0u;
+    s.w2 = ring[((s.next - 4u) & RING_MASK) >> 2];
+    s.hist = inrun ? h : hv;
+    s.signmod = inrun ? s.signmod : 0;
+    s.zrun -= inrun ? 1 : 0;
+    return r;
+}
 constexpr int SPEC_UNIT = 4;   // steps per speculative unit
 
 // ---- per-row LDS ring ------------------------------------------------------------------------------

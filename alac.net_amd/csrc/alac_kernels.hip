@@ -302,13 +302,20 @@ __device__ void entropy_wave(const alac_decode_params& p, uint32_t pkt0, int lan
             int i = 0;
             for (; i + CHUNK <= nmin - 1; i += CHUNK) {   // every lane has a sample left after each of these
                 for (int u = 0; u < CHUNK; u += SPEC_UNIT) {
-                    bool redo = __builtin_amdgcn_ballot_w64(rs.nforce == 0u) != 0;
-                    if (!redo) {
+                    bool redo = false;
+                    {
+                        const bool special = __builtin_amdgcn_ballot_w64(rs.nforce == 0u) != 0;
                         const Rice snap = rs;
                         uint32_t xmax = 0;
                         int hmin = 0x7FFFFFFF;
+                        if (!special) {
 #pragma unroll
-                        for (int ii = 0; ii < SPEC_UNIT; ii++) (void)rice_spec_step<false>(rs, pc, pring, xmax, hmin);
+                            for (int ii = 0; ii < SPEC_UNIT; ii++) (void)rice_spec_step<false>(rs, pc, pring, xmax, hmin);
+                        } else {
+#pragma unroll
+                            for (int ii = 0; ii < SPEC_UNIT; ii++) (void)rice_spec_step_z<false>(rs, pc, pring, xmax, hmin);
+                            rs.nforce = (rs.zrun > 0 || rs.signmod != 0) ? 0u : 0xFFFFFFFFu;
+                        }
                         if (__builtin_expect(__builtin_amdgcn_ballot_w64(xmax > 8u || hmin < 128) != 0, 0)) {
                             rs = snap;
                             redo = true;
@@ -371,14 +378,22 @@ __device__ void entropy_wave(const alac_decode_params& p, uint32_t pkt0, int lan
         if (i0 < nmax) {
             if (i0 + CHUNK <= nmin - 1) {                  // fast chunk: all lanes decode, a sample always remains
                 for (int u = 0; u < CHUNK; u += SPEC_UNIT) {
-                    bool redo = __builtin_amdgcn_ballot_w64(rs.nforce == 0u) != 0;
-                    if (!redo) {
+                    bool redo = false;
+                    {
+                        const bool special = __builtin_amdgcn_ballot_w64(rs.nforce == 0u) != 0;
                         const Rice snap = rs;
                         uint32_t xmax = 0;
                         int hmin = 0x7FFFFFFF;
+                        if (!special) {
 #pragma unroll
-                        for (int ii = 0; ii < SPEC_UNIT; ii++)
-                            q[(u + ii) * S] = rice_spec_step<true>(rs, mc, mring, xmax, hmin);
+                            for (int ii = 0; ii < SPEC_UNIT; ii++)
+                                q[(u + ii) * S] = rice_spec_step<true>(rs, mc, mring, xmax, hmin);
+                        } else {   // some lane is inside a zero run: the run-aware straight-line step
+#pragma unroll
+                            for (int ii = 0; ii < SPEC_UNIT; ii++)
+                                q[(u + ii) * S] = rice_spec_step_z<true>(rs, mc, mring, xmax, hmin);
+                            rs.nforce = (rs.zrun > 0 || rs.signmod != 0) ? 0u : 0xFFFFFFFFu;
+                        }
                         if (__builtin_expect(__builtin_amdgcn_ballot_w64(xmax > 8u || hmin < 128) != 0, 0)) {
                             rs = snap;
                             redo = true;
