@@ -218,6 +218,9 @@ extern "C" __global__ __launch_bounds__(64) void alac_decode_packets_kernel(alac
 namespace {
 
 constexpr int CHUNK = 16;
+#ifndef ALAC_ENTROPY_PRIO
+#define ALAC_ENTROPY_PRIO 3
+#endif
 
 template <int F>
 struct SplitShared {
@@ -629,7 +632,7 @@ __device__ __forceinline__ void split_kernel_body(const alac_decode_params& p) {
     wg_sync();
     if (wave == 0) {
         // the entropy wave is the longest dependent chain of the workgroup: let it win issue arbitration
-        __builtin_amdgcn_s_setprio(3);
+        __builtin_amdgcn_s_setprio(ALAC_ENTROPY_PRIO);
         entropy_wave<F>(p, pkt0, lane, sh, nchunks);
     }
     else {

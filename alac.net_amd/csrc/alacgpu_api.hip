@@ -57,7 +57,10 @@ int ensure_ws(alacgpu_ctx* ctx, size_t bytes) {
 int launch(alacgpu_ctx* ctx, const alac_decode_params& p, hipStream_t stream) {
     if (p.n_packets == 0) return ALACGPU_OK;
     int variant = ctx->variant;
-    if (variant == 0) variant = 3;  // auto: split kernel, 1 entropy + 2 reconstruction waves (4 packets / WG)
+    // auto: up to ~4 workgroups per CU the 4-packet workgroup (1 entropy + 2 reconstruction waves) has the
+    // shortest critical path; bigger batches are throughput bound and do better with 8 packets per workgroup
+    // (half as many entropy waves).  Measured on MI355X: cfg2 (4096 packets) 1.43 vs 1.51 ms, cfg3 (8192) 9.4 vs 7.0 ms.
+    if (variant == 0) variant = p.n_packets >= 6144 ? 4 : 3;
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
     switch (variant) {
     case 1:

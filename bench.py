@@ -30,8 +30,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=2, help="BASELINE.json config number (2..5)")
     ap.add_argument("--packets", type=int, default=None, help="packets per GPU (default: the config's batch)")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 auto, 1 fused, 2/3/4 split)")
@@ -175,6 +175,17 @@ def main():
         }
 
     if rank == 0:
+        auto = 4 if n_packets >= 6144 else 3   # mirrors the library's auto choice (alacgpu_api.hip: launch)
+        kernel_name = {1: "alac_decode_packets_kernel", 2: "alac_decode_split1_kernel", 3: "alac_decode_split2_kernel",
+                       4: "alac_decode_split4_kernel"}[args.variant or auto]
+        # HBM traffic comes from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read in-process):
+        # the committed measurement of the same workload + kernel, see profiles/
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", f"traffic_cfg{args.config}.json")
+        if os.path.exists(tfile) and args.packets is None:
+            tj = json.load(open(tfile))
+            if tj.get("kernel") == kernel_name:
+                traffic = tj["hbm_bytes_per_launch"]
         ms_per_step = elapsed / args.steps * 1e3
         value = total_samples_per_step * args.steps / elapsed / 1e6
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
@@ -190,9 +201,8 @@ def main():
             "config": {"workload": names[args.config], "packets_per_gpu": n_packets,
                        "samples_per_step_per_gpu": samples_per_step, "parallelism": f"packet-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                         "kernel": {0: "alac_decode_split2_kernel", 1: "alac_decode_packets_kernel", 2: "alac_decode_split1_kernel",
-                                    3: "alac_decode_split2_kernel", 4: "alac_decode_split4_kernel"}[args.variant], "kernel_ms": round(kernel_ms, 4),
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "kernel": kernel_name, "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": algo_bytes},
             "cpu_baseline": cpu_baseline,
             "parity_vs_oracle": parity, "status_ok": status_ok, "allgather_ms": allgather_ms,
