@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 auto, 1 fused, 2/3/4 split)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-allgather", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 path)")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -46,13 +48,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     distributed = world > 1
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")   # where collective operands live
     if distributed:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     import alac.net_amd as pkg
     from alac.net_amd import synth
@@ -115,32 +123,34 @@ def main():
     kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in evs]))
 
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        k = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
+        k = torch.tensor([kernel_ms], dtype=torch.float64, device=cdev)
         dist.all_reduce(k, op=dist.ReduceOp.MAX)
         kernel_ms = float(k.item())
-        tot = torch.tensor([samples_per_step], dtype=torch.int64, device=dev)
+        tot = torch.tensor([samples_per_step, algo_bytes], dtype=torch.int64, device=cdev)
         dist.all_reduce(tot)
-        total_samples_per_step = int(tot.item())
+        total_samples_per_step = int(tot[0].item())
     else:
         total_samples_per_step = samples_per_step
 
     # ---- decoded-PCM all-gather over RCCL/xGMI (outside the timed region; reported separately) ----
     allgather_ms = None
     if distributed and not args.no_allgather:
-        gathered = torch.empty((world * n_packets, slot), dtype=torch.int32, device=dev)
-        dist.all_gather_into_tensor(gathered, d_pcm)
+        from alac.net_amd import sharding
+
+        src = d_pcm if args.backend == "nccl" else d_pcm.cpu()
+        gathered = sharding.allgather_pcm(src, world * n_packets)
         torch.cuda.synchronize(dev)
         dist.barrier()
         t1 = time.perf_counter()
         reps = 3
         for _ in range(reps):
-            dist.all_gather_into_tensor(gathered, d_pcm)
+            gathered = sharding.allgather_pcm(src, world * n_packets)
         torch.cuda.synchronize(dev)
         allgather_ms = (time.perf_counter() - t1) / reps * 1e3
-        assert torch.equal(gathered[rank * n_packets:(rank + 1) * n_packets], d_pcm)
+        assert torch.equal(gathered[rank * n_packets:(rank + 1) * n_packets], src)
         del gathered
 
     # ---- correctness + CPU baseline (rank 0, N=1 only; the oracle is the checker, never the product) ----
