@@ -1,0 +1,98 @@
+"""Demuxer -> batch feeder -> AlacContext surface, against files made by the
+M4A writer in alac.net_amd/synth/m4a.py (the reference ships no files)."""
+import io
+
+import numpy as np
+import pytest
+
+
+def make_file(synth, n_packets=23, sample_size=16, stereo=True, last=1234, seed=5, **kw):
+    from alac.net_amd.synth import m4a
+
+    d = synth.packet_descs(n_packets, sample_size=sample_size, stereo=int(stereo), pred_order=8 if sample_size == 16 else 16)
+    d["n"][-1] = last
+    b = synth.make_batch(d, synth.default_signal(seed), want_pcm=True)
+    packets = [bytes(b["blob"][int(o):int(o) + int(s)]) for o, s in zip(b["offsets"], b["sizes"])]
+    data = m4a.write_m4a(packets, [int(x) for x in d["n"]], sample_size=sample_size, channels=2 if stereo else 1, **kw)
+    ch = 2 if stereo else 1
+    pcm = np.concatenate([b["pcm"][p, : int(d["n"][p]) * ch] for p in range(n_packets)])
+    return data, packets, pcm, d
+
+
+def test_demuxer_tables(synth):
+    from alac.net_amd import container
+
+    data, packets, pcm, d = make_file(synth)
+    res = container.DemuxResT()
+    st = container.QtMovieT(container._Stream(io.BytesIO(data)), res).ReadHeader()
+    assert st == container.MDAT_OK
+    assert (res.SampleSize, res.NumChannels, res.SampleRate) == (16, 2, 44100)
+    assert res.SampleByteSize.tolist() == [len(p) for p in packets]
+    assert res.TimeToSample == [(22, 4096), (1, 1234)]
+    assert res.Stsc == [(1, 5, 1), (5, 3, 1)] and len(res.Stco) == 5
+    assert res.MdatLen == sum(len(p) for p in packets)
+    # CodecData feeds SetInfo unchanged (AlacFile.cs:63-93)
+    import alac.net_amd as pkg
+    cfg = pkg.cfg_from_codec_data(res.CodecData[:48], res.SampleSize, res.NumChannels)
+    assert [int(cfg[k][0]) for k in ("max_samples_per_frame", "sample_size", "rice_history_mult", "rice_initial_history",
+                                     "rice_kmodifier", "num_channels")] == [4096, 16, 40, 10, 14, 2]
+    # first chunk offset points at the first packet
+    assert data[res.Stco[0]: res.Stco[0] + len(packets[0])] == packets[0]
+
+
+def test_mdat_before_moov_is_rejected_like_the_reference(synth):
+    # QTMovieT.cs:746 compares Seek()'s return value (the new position) with 0 -> such files never load
+    from alac.net_amd import container
+
+    data, *_ = make_file(synth, n_packets=3, mdat_first=True)
+    res = container.DemuxResT()
+    assert container.QtMovieT(container._Stream(io.BytesIO(data)), res).ReadHeader() == container.MDAT_CANNOT_SEEK
+
+
+def test_unknown_atoms_fail(synth):
+    from alac.net_amd import container
+
+    data, *_ = make_file(synth, n_packets=2)
+    bad = data.replace(b"smhd", b"vmhd")
+    assert container.QtMovieT(container._Stream(io.BytesIO(bad)), container.DemuxResT()).ReadHeader() == container.MDAT_NONE
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sample_size,stereo", [(16, True), (24, True), (16, False)])
+def test_alaccontext_read_loop_equals_source_pcm(synth, sample_size, stereo):
+    # the reference's playback loop: while ((n = ctx.Read(buf)) > 0) consume(buf, n)
+    from alac.net_amd import container
+
+    data, packets, pcm, d = make_file(synth, sample_size=sample_size, stereo=stereo)
+    with container.AlacContext(io.BytesIO(data), batch_packets=7) as ctx:
+        assert ctx.GetNumSamples() == int(d["n"].sum())
+        assert (ctx.GetBitsPerSample(), ctx.GetNumChannels(), ctx.GetSampleRate()) == (sample_size, 2 if stereo else 1, 44100)
+        buf = np.zeros(1024 * 80, dtype=np.uint8)
+        out = bytearray()
+        while True:
+            n = ctx.Read(buf)
+            if n <= 0:
+                break
+            out += bytes(buf[:n])
+        assert ctx.LastSampleNumber == int(d["n"].sum())
+    bps = sample_size // 8
+    exp = b"".join(int(v).to_bytes(4, "little", signed=True)[:bps] for v in pcm)
+    assert bytes(out) == exp
+
+
+@pytest.mark.gpu
+def test_alaccontext_seek(synth):
+    from alac.net_amd import container
+
+    data, packets, pcm, d = make_file(synth, n_packets=13, last=4096)
+    with container.AlacContext(io.BytesIO(data), batch_packets=4) as ctx:
+        buf = np.zeros(1024 * 80, dtype=np.uint8)
+        ctx.Read(buf)
+        for pos in (4096 * 6 + 100, 17, 4096 * 12 + 4000):
+            ctx.SetPosition(pos)
+            n = ctx.Read(buf)
+            frame = pos // 4096
+            # the rest of that frame, starting at the requested sample (16-bit: offset = samples * channels ints)
+            exp = pcm[pos * 2:(frame + 1) * 4096 * 2].astype("<i2").tobytes()
+            assert n == len(exp) and bytes(buf[:n]) == exp
+            assert ctx.LastSampleNumber == (frame + 1) * 4096
