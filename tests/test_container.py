@@ -95,4 +95,6 @@ def test_alaccontext_seek(synth):
             # the rest of that frame, starting at the requested sample (16-bit: offset = samples * channels ints)
             exp = pcm[pos * 2:(frame + 1) * 4096 * 2].astype("<i2").tobytes()
             assert n == len(exp) and bytes(buf[:n]) == exp
-            assert ctx.LastSampleNumber == (frame + 1) * 4096
+            # SetPosition sets LastSampleNumber to the END of the frame (AlacContext.cs:283) and the following Read
+            # adds the frame's duration once more (:199): the reference's double count, reproduced
+            assert ctx.LastSampleNumber == (frame + 2) * 4096
