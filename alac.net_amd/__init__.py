@@ -49,6 +49,7 @@ SYMBOLS = {
     "alacgpu_format_samples": (C.c_size_t, [C.c_int, _VP, C.c_int32, _VP]),
     "alacgpu_last_kernel_ms": (C.c_float, [_VP]),
     "alacgpu_set_kernel_variant": (C.c_int, [_VP, C.c_int]),
+    "alacgpu_set_output_format": (C.c_int, [_VP, C.c_int]),
     "alacgpu_strerror": (C.c_char_p, [C.c_int]),
     "alacgpu_status_string": (C.c_char_p, [C.c_int]),
     "alacgpu_last_error": (C.c_char_p, [_VP]),
@@ -168,6 +169,11 @@ class AlacGpuContext:
                                                dp(d_cfg_idx), n_packets, dp(d_pcm), slot_ints, dp(d_out_bytes),
                                                dp(d_out_samples), dp(d_status), _VP(stream))
         _check(rc, self._ctx)
+
+    def set_output_format(self, fmt):
+        """0: int32 per sample (default).  1: packed little-endian PCM bytes (FormatSamples fused into the store);
+        packet p's bytes are pcm[p].view(uint8)[:out_bytes[p]]."""
+        _check(lib().alacgpu_set_output_format(self._ctx, fmt), self._ctx)
 
     def set_kernel_variant(self, variant):
         """0 auto, 1 fused kernel, 2/3/4 split kernel with 1/2/4 reconstruction waves (results identical)."""

@@ -37,6 +37,7 @@ struct alac_decode_params {
     int32_t* out_bytes;         // may be null
     int32_t* out_samples;       // may be null
     int32_t* status;
+    uint32_t out_format;        // 0: one int32 per sample; 1: packed little-endian PCM bytes (FormatSamples fused)
     unsigned long long* dbg;    // diagnostic builds only: per-workgroup s_memtime stamps (null in normal use)
 };
 

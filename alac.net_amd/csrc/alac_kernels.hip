@@ -30,8 +30,25 @@ using namespace alacdev;
 
 namespace {
 
+// Output store.  out_format 0: the canonical int32 per sample.  out_format 1: what AlacContext.Read hands
+// out -- FormatSamples (AlacContext.cs:214-256) fused into the store: 16-bit streams the low 16 bits little-endian
+// (:231-242), 24-bit streams the three bytes of the sample (:244-252 over the byte-per-int layout).
+__device__ __forceinline__ void store_sample(const alac_decode_params& p, const Meta& m, int32_t* pcm_slot, int64_t idx,
+                                             int val) {
+    if (p.out_format == 0) {
+        pcm_slot[idx] = val;
+    } else if (m.ss == 16) {
+        reinterpret_cast<uint16_t*>(pcm_slot)[idx] = (uint16_t)val;
+    } else {
+        uint8_t* b = reinterpret_cast<uint8_t*>(pcm_slot) + idx * 3;
+        b[0] = (uint8_t)val;
+        b[1] = (uint8_t)(val >> 8);
+        b[2] = (uint8_t)(val >> 16);
+    }
+}
+
 template <int TPL>
-__device__ void decode_wave(const Meta& m, const alacgpu_cfg_dev& cfg, bool valid, int row, int l, int lane, int chan,
+__device__ void decode_wave(const alac_decode_params& p, const Meta& m, const alacgpu_cfg_dev& cfg, bool valid, int row, int l, int lane, int chan,
                             uint32_t* ring, int32_t* pcm_slot, int32_t* st_out, uint32_t pkt) {
     const bool compressed = valid && m.status == 0 && !m.esc;
     const bool stream_on = compressed && (chan == 0 || m.stereo);
@@ -141,7 +158,7 @@ __device__ void decode_wave(const Meta& m, const alacgpu_cfg_dev& cfg, bool vali
                 }
                 val = __builtin_amdgcn_sbfe(val, 0, 24);
             }
-            if (chan < m.nc) pcm_slot[(int64_t)i * m.nc + chan] = val;
+            if (chan < m.nc) store_sample(p, m, pcm_slot, (int64_t)i * m.nc + chan, val);
         }
     }
 
@@ -195,9 +212,9 @@ extern "C" __global__ __launch_bounds__(64) void alac_decode_packets_kernel(alac
     // two tap registers per lane only when some stream in this wave needs more than 16 taps
     const bool wide = valid && m.status == 0 && !m.esc && m.N > 16 && m.N <= 30 && (chan == 0 || m.stereo);
     if (__builtin_amdgcn_ballot_w64(wide))
-        decode_wave<2>(m, cfg, valid, row, l, lane, chan, ring, pcm_slot, p.status, pkt);
+        decode_wave<2>(p, m, cfg, valid, row, l, lane, chan, ring, pcm_slot, p.status, pkt);
     else
-        decode_wave<1>(m, cfg, valid, row, l, lane, chan, ring, pcm_slot, p.status, pkt);
+        decode_wave<1>(p, m, cfg, valid, row, l, lane, chan, ring, pcm_slot, p.status, pkt);
 }
 
 // =====================================================================================================
@@ -498,7 +515,7 @@ __device__ __forceinline__ void recon_output(const alac_decode_params& p, const 
             }
             val = __builtin_amdgcn_sbfe(val, 0, 24);
         }
-        if (chan < m.nc) pcm_slot[(int64_t)i * m.nc + chan] = val;
+        if (chan < m.nc) store_sample(p, m, pcm_slot, (int64_t)i * m.nc + chan, val);
     }
 }
 

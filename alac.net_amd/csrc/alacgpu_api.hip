@@ -21,6 +21,7 @@ struct alacgpu_ctx {
     hipStream_t stream = nullptr;      // used by the host-buffer entry points
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    uint32_t out_format = 0;           // 0 int32 per sample, 1 packed little-endian PCM
     int variant = 0;                   // 0 auto, 1 fused (v1), 2/3/4 split with 1/2/4 reconstruction waves
     // grow-only device workspace for the host-buffer entry points
     void* d_ws = nullptr;
@@ -204,6 +205,7 @@ int alacgpu_decode_batch_device(alacgpu_ctx* ctx, const void* d_blob, uint64_t b
     p.out_bytes = (int32_t*)d_out_bytes;
     p.out_samples = (int32_t*)d_out_samples;
     p.status = (int32_t*)d_status;
+    p.out_format = ctx->out_format;
     p.dbg = nullptr;
     if (std::getenv("ALACGPU_DEBUG_STAMPS")) {  // diagnostic: per-WG phase stamps, printed to stderr (blocks)
         const uint32_t nwg = (n_packets + 1) / 2;
@@ -317,7 +319,10 @@ int alacgpu_decode_frame(alacgpu_ctx* ctx, uint32_t cfg_index, const uint8_t* in
     const uint64_t off = 0;
     const uint16_t ci = (uint16_t)cfg_index;
     int32_t ob = 0, os = 0, st = 0;
+    const uint32_t saved_format = ctx->out_format;
+    ctx->out_format = ALACGPU_OUT_INT32;
     int rc = alacgpu_decode_batch(ctx, inbuffer, in_bytes, &off, &in_bytes, &ci, 1, pcm, slot, &ob, &os, &st);
+    ctx->out_format = saved_format;
     if (rc == ALACGPU_OK) {
         *status = st;
         if (out_bytes) *out_bytes = ob;
@@ -329,6 +334,12 @@ int alacgpu_decode_frame(alacgpu_ctx* ctx, uint32_t cfg_index, const uint8_t* in
     }
     std::free(pcm);
     return rc;
+}
+
+int alacgpu_set_output_format(alacgpu_ctx* ctx, int format) {
+    if (!ctx || (format != ALACGPU_OUT_INT32 && format != ALACGPU_OUT_PACKED_LE)) return ALACGPU_ERR_BAD_ARG;
+    ctx->out_format = (uint32_t)format;
+    return ALACGPU_OK;
 }
 
 int alacgpu_set_kernel_variant(alacgpu_ctx* ctx, int variant) {

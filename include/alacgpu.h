@@ -119,6 +119,13 @@ size_t alacgpu_format_samples(int bytes_per_sample, const int32_t* ref_ints, int
  * on the launch stream (milliseconds; < 0 if unavailable).  Synchronises the stream. */
 float alacgpu_last_kernel_ms(alacgpu_ctx* ctx);
 
+/* Output layout of the batch entry points.  ALACGPU_OUT_INT32 (default): one int32 per sample, as documented
+ * above.  ALACGPU_OUT_PACKED_LE: the bytes AlacContext.Read hands out -- AlacContext.FormatSamples
+ * (AlacContext.cs:214-256) fused into the kernel's store: packet p's little-endian PCM (2 or 3 bytes per sample,
+ * interleaved) starts at (uint8_t*)(pcm_out + p*slot_ints) and is out_bytes[p] long.  The slot stride is unchanged. */
+enum { ALACGPU_OUT_INT32 = 0, ALACGPU_OUT_PACKED_LE = 1 };
+int alacgpu_set_output_format(alacgpu_ctx* ctx, int format);
+
 /* Tuning / A-B knob (no effect on results): 0 = auto (default), 1 = fused single-wave kernel,
  * 2 / 3 / 4 = split kernel with 1 / 2 / 4 reconstruction waves per workgroup.  Also settable with the
  * environment variable ALACGPU_KERNEL_VARIANT at create time. */

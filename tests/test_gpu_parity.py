@@ -267,3 +267,26 @@ def test_cpp_host_mirror(pkg, oracle, synth, tmp_path):
     # error behaviour: sample size 20 -> the reference's exception text
     out = subprocess.run([exe, str(path), "20", "2"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 1 and "FIXME: unimplemented sample size 20" in out.stdout
+
+
+@pytest.mark.parametrize("variant", [1, 3, 4])
+@pytest.mark.parametrize("cfg", [2, 3, 4, 5])
+def test_packed_output_equals_format_samples(pkg, oracle, synth, cfg, variant):
+    # ALACGPU_OUT_PACKED_LE: the kernel stores what AlacContext.Read returns (FormatSamples fused, AlacContext.cs:214-256)
+    b = synth.make_config_batch(cfg, n_packets=48)
+    cfgs = oracle.make_cfgs(b["stream_cfgs"])
+    opcm, oob, oos, ost = oracle.decode_batch(cfgs, b["blob"], b["offsets"], b["sizes"], b["cfg_idx"], b["slot_ints"], n_threads=8)
+    with pkg.AlacGpuContext(b["stream_cfgs"]) as ctx:
+        ctx.set_kernel_variant(variant)
+        ctx.set_output_format(1)
+        pcm, ob, os_, st = ctx.decode_batch(b["blob"], b["offsets"], b["sizes"], b["cfg_idx"], b["slot_ints"])
+    assert np.array_equal(st, ost) and np.array_equal(ob, oob)
+    raw = pcm.view(np.uint8)
+    for p in range(len(st)):
+        if ost[p] != 0:
+            continue
+        ci = 0 if b["cfg_idx"] is None else int(b["cfg_idx"][p])
+        row = cfgs[ci:ci + 1]
+        ref = oracle.expand_reference_layout(row, opcm[p], int(oos[p]))
+        exp = oracle.format_samples(int(row["sample_size"][0]) // 8, ref, int(oob[p]))
+        assert np.array_equal(raw[p, : len(exp)], exp), f"packet {p}"
