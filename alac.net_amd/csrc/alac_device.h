@@ -421,6 +421,63 @@ __device__ __forceinline__ void fir_fast(FirLane& f, int err) {
     f.base = nb;
 }
 
+// ---- "P8" layout: 8 lanes per stream, the two channels of a packet interleaved in one row -----------------
+// For streams with 1 <= N <= 8.  Row r = packet r of the wave; lane l of the row: channel = l & 1, tap j = l >> 1.
+// Every DPP pattern below moves data between lanes of equal parity, i.e. inside one stream: the dot product is
+// quad_perm[2,3,0,1] + row_ror:4 + row_ror:8, the suffix scan row_shl:2/4/8 (zero fill), the history shift
+// row_shr:2 (lanes 0/1 take the new output), and the A/B partner of a sample is lane ^ 1.  One wave so serves 8
+// streams = 4 packets instead of 2, which halves the reconstruction instructions per packet.
+constexpr int DPP_ROW_SHL_2 = 0x102, DPP_ROW_SHL_4 = 0x104, DPP_ROW_SHL_8 = 0x108, DPP_ROW_SHR2 = 0x112;
+constexpr int DPP_ROW_ROR4 = 0x124, DPP_ROW_ROR8 = 0x128;
+
+struct Fir8Lane {
+    int hist, coef, base, prev;
+    int q, rnd, rss, qmask;   // per stream
+    int N;
+    uint32_t w;               // N - j for tap j < N, else 0
+    int tlo, thi;             // -1 / +1 on tap lanes, 0 / 0 elsewhere
+    int bpaddr;               // ds_bpermute byte address of the lane holding tap N-1 of this stream
+};
+
+// GENERIC = false: steady state (every stream of the wave switched on, i > N).  GENERIC = true: also the first
+// sample / warm-up samples (:284-293) and streams that are switched off or already finished (`active` false).
+template <bool NARROW, bool GENERIC>
+__device__ __forceinline__ void fir8_step(Fir8Lane& f, int err, int i, bool active) {
+    const int nb = __builtin_amdgcn_ds_bpermute(f.bpaddr, f.hist);
+    const int d = wsub(f.hist, f.base);                                       // :303
+    int p = NARROW ? __mul24(d, f.coef) : wmul(d, f.coef);
+    p = wadd(p, dpp0<DPP_QUAD_2301>(p));
+    p = wadd(p, __builtin_amdgcn_update_dpp(0, p, DPP_ROW_ROR4, 0xF, 0xF, false));
+    p = wadd(p, __builtin_amdgcn_update_dpp(0, p, DPP_ROW_ROR8, 0xF, 0xF, false));
+    int out = __builtin_amdgcn_sbfe(wadd(wadd(wadd(f.rnd, p) >> f.q, f.base), err), 0, f.rss);  // :306-310
+    bool general = true;
+    if (GENERIC) {
+        general = i > f.N;
+        if (i == 0) out = err;                                                // first sample copies
+        else if (!general) out = __builtin_amdgcn_sbfe(wadd(f.prev, err), 0, f.rss);  // warm-up :284-293
+    }
+    const int s = err >> 31;
+    const int a = max(d, -d);
+    const uint32_t aq = (uint32_t)(a + (s & f.qmask)) >> f.q;
+    uint32_t cc = NARROW ? __umul24(aq, f.w) : aq * f.w;
+    cc = min(cc, 1u << 26);
+    uint32_t incl = cc;
+    incl += (uint32_t)dpp0<DPP_ROW_SHL_2>((int)incl);
+    incl += (uint32_t)dpp0<DPP_ROW_SHL_4>((int)incl);
+    incl += (uint32_t)dpp0<DPP_ROW_SHL_8>((int)incl);
+    const uint32_t Ecc = (uint32_t)((err ^ s) - s) + cc;
+    int sd;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(sd) : "v"(d), "v"(f.tlo), "v"(f.thi));
+    const bool visit = (Ecc > incl) && (!GENERIC || (general && active));
+    f.coef += visit ? (sd ^ s) - s : 0;
+    const int shifted = __builtin_amdgcn_update_dpp(out, f.hist, DPP_ROW_SHR2, 0xF, 0xF, false);
+    if (!GENERIC || active) {
+        f.hist = shifted;
+        f.base = nb;
+        f.prev = out;
+    }
+}
+
 // Everything a lane knows about its packet / stream after the header parse.
 struct Meta {
     const uint8_t* base;   // 16-byte aligned-down packet start

@@ -613,8 +613,144 @@ __device__ void recon_wave_impl(const alac_decode_params& p, const Meta& m, bool
     }
 }
 
+// Reconstruction wave in the P8 layout (see alac_device.h): 8 streams = 4 packets per wave.
+template <int F>
+__device__ void recon8_wave(const alac_decode_params& p, uint32_t pkt0, int w8, int lane, SplitShared<F>& sh, int nchunks,
+                            bool narrow) {
+    constexpr int S = 4 * F;
+    const int row = lane >> 4, l = lane & 15, chan = l & 1, j = l >> 1;
+    const int g = 8 * w8 + 2 * row + chan;                 // stream index inside the workgroup
+    const uint32_t pkt = pkt0 + (uint32_t)(g >> 1);
+    const bool valid = pkt < p.n_packets;
+    alacgpu_cfg_dev cfg;
+    const Meta m = parse_meta(p, pkt, chan, valid, cfg);
+    const bool compressed = valid && m.status == 0 && !m.esc;
+    const bool stream_on = compressed && (chan == 0 || m.stereo);
+    const int n_row = stream_on ? m.n : 0;
+    const int n_out = (valid && m.status == 0) ? m.n : 0;
+    int32_t* pcm_slot = p.pcm_out + (int64_t)pkt * p.slot_ints;
+
+    Fir8Lane f;
+    f.hist = 0;
+    f.coef = (stream_on && j < m.N) ? (int)(int16_t)peek_bits(m.base, m.limit, m.coefbit + 16u * j, 16) : 0;
+    f.base = 0;
+    f.prev = 0;
+    f.q = stream_on ? m.q : 1;
+    f.rnd = stream_on ? m.rnd : 0;
+    f.rss = stream_on ? m.rss : 16;
+    f.qmask = (1 << f.q) - 1;
+    f.N = stream_on ? m.N : 0;
+    const bool tap = stream_on && j < m.N;
+    f.tlo = tap ? -1 : 0;
+    f.thi = tap ? 1 : 0;
+    f.w = tap ? (uint32_t)(m.N - j) : 0u;
+    f.bpaddr = ((lane & 48) + 2 * (stream_on ? (m.N - 1) & 7 : 0) + chan) * 4;
+
+    const int nmax = __builtin_amdgcn_readfirstlane(wave_max(n_row));
+    const int nmin = __builtin_amdgcn_readfirstlane(-wave_max(stream_on ? -m.n : -0x7FFFFFFF));
+    const int* qzero = &sh.zeros[0][g];
+
+    for (int c = 0; c < nchunks; c++) {
+        const int i0 = c * CHUNK;
+        wg_sync();  // wait for chunk c
+        const int* q = stream_on ? &sh.resq[c & 1][0][g] : qzero;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {             // 8 lanes of history per stream: output every 8 steps
+            const int ih = i0 + 8 * half;
+            if (ih < nmax) {
+                if (ih > 8 && ih + 8 <= nmin) {   // every switched-on stream is past its warm-up and has 8 samples left
+                    int err = q[(8 * half) * S];
+                    if (narrow) {
+#pragma unroll
+                        for (int ii = 0; ii < 8; ii++) {
+                            const int en = q[(8 * half + (ii < 7 ? ii + 1 : ii)) * S];
+                            fir8_step<true, false>(f, err, ih + ii, true);
+                            err = en;
+                        }
+                    } else {
+#pragma unroll
+                        for (int ii = 0; ii < 8; ii++) {
+                            const int en = q[(8 * half + (ii < 7 ? ii + 1 : ii)) * S];
+                            fir8_step<false, false>(f, err, ih + ii, true);
+                            err = en;
+                        }
+                    }
+                } else {
+                    for (int ii = 0; ii < 8; ii++) {
+                        const int i = ih + ii;
+                        const int err = q[(8 * half + ii) * S];
+                        if (narrow) fir8_step<true, true>(f, err, i, i < n_row);
+                        else fir8_step<false, true>(f, err, i, i < n_row);
+                    }
+                }
+            }
+            // ---- output: lane (2t + chan) of the row holds out[last - t] ----
+            const int cnt = min(8, n_out - ih);
+            const bool live = j < cnt;
+            const int i = m.esc ? ih + j : ih + cnt - 1 - j;
+            int mine = f.hist;
+            if (live && m.esc && (chan == 0 || m.stereo)) {
+                const uint32_t bp = m.rawbit + (uint32_t)((i * (m.stereo ? 2 : 1) + chan) * m.ss);
+                mine = __builtin_amdgcn_sbfe((int)peek_bits(m.base, m.limit, bp, m.ss), 0, m.ss);
+            }
+            const int partner = __builtin_amdgcn_update_dpp(0, mine, DPP_QUAD_1032, 0xF, 0xF, false);
+            if (live) {
+                const int a = chan == 0 ? mine : partner, b = chan == 0 ? partner : mine;
+                int val;
+                if (m.stereo) {
+                    int left, right;
+                    if (m.mixweight != 0) {
+                        right = wsub(a, wmul(b, m.mixweight) >> (m.mixshift & 31));
+                        left = wadd(right, b);
+                    } else {
+                        left = a;
+                        right = b;
+                    }
+                    val = chan == 0 ? left : right;
+                } else {
+                    val = chan == 0 ? a : 0;
+                }
+                if (m.ss == 24) {
+                    if (m.ub != 0 && !m.esc && (chan == 0 || m.stereo)) {
+                        const uint32_t bp = m.ubit + (uint32_t)((i * (m.stereo ? 2 : 1) + chan) * 8 * m.ub);
+                        const uint32_t sb = peek_bits(m.base, m.limit, bp, 8 * m.ub);
+                        val = (int)(((uint32_t)val << (8 * m.ub)) | sb);
+                    }
+                    val = __builtin_amdgcn_sbfe(val, 0, 24);
+                }
+                if (chan < m.nc) store_sample(p, m, pcm_slot, (int64_t)i * m.nc + chan, val);
+            }
+        }
+    }
+}
+
 template <int F>
 __device__ void recon_wave(const alac_decode_params& p, uint32_t pkt0, int w, int lane, SplitShared<F>& sh, int nchunks) {
+    // ---- can the whole workgroup use the P8 layout?  Every wave evaluates all 4F streams the same way. ----
+    bool p8 = true, narrow8 = true;
+    {
+        constexpr int S = 4 * F;
+#pragma unroll
+        for (int base = 0; base < S; base += 64) {
+            const int gg = base + (lane % S);
+            const uint32_t pk = pkt0 + (uint32_t)(gg >> 1);
+            const bool v = pk < p.n_packets;
+            alacgpu_cfg_dev c;
+            const Meta mm = parse_meta(p, pk, gg & 1, v, c);
+            const bool on = v && mm.status == 0 && !mm.esc && ((gg & 1) == 0 || mm.stereo);
+            const bool bad = on && (mm.N < 1 || mm.N > 8);
+            if (__builtin_amdgcn_ballot_w64(bad)) p8 = false;
+            if (__builtin_amdgcn_ballot_w64(on && mm.rss > 17)) narrow8 = false;
+        }
+    }
+    if (p8 && F >= 2) {
+        if (w < F / 2) {
+            recon8_wave<F>(p, pkt0, w, lane, sh, nchunks, narrow8);
+        } else {
+            for (int c = 0; c < nchunks; c++) wg_sync();   // nothing to do: keep the barrier count
+        }
+        return;
+    }
     const int row = lane >> 4;
     const int g = 4 * w + row;
     const int chan = g & 1;

@@ -290,3 +290,23 @@ def test_packed_output_equals_format_samples(pkg, oracle, synth, cfg, variant):
         ref = oracle.expand_reference_layout(row, opcm[p], int(oos[p]))
         exp = oracle.format_samples(int(row["sample_size"][0]) // 8, ref, int(oob[p]))
         assert np.array_equal(raw[p, : len(exp)], exp), f"packet {p}"
+
+
+@pytest.mark.parametrize("variant", [3, 4])
+@pytest.mark.parametrize("stereo,is24", [(True, False), (True, True), (False, False)])
+def test_p8_layout_random(pkg, oracle, synth, variant, stereo, is24):
+    # every stream has 1 <= N <= 8, so the split kernels use the 8-lanes-per-stream reconstruction layout;
+    # ragged sample counts, escapes, silence and loud content exercise its generic (masked) steps too
+    rng = np.random.default_rng(808 + stereo + 2 * is24)
+    count = 80
+    d = _random_recipe_batch(synth, 99 + stereo, count, stereo, is24)
+    d["pred_order"] = rng.integers(1, 9, (count, 2))
+    d["n"][:8] = [1, 7, 8, 9, 15, 16, 17, 4096]
+    sig = synth.default_signal(4242)
+    sig["silence_prob"] = 0.4
+    sig["amp_lo_log2"], sig["amp_hi_log2"], sig["noise_sigma"] = 13.0, 15.0, 3000.0
+    b = synth.make_batch(d, sig, want_pcm=True)
+    b.update(stream_cfgs=[(4096, 24 if is24 else 16, 40, 10, 14, 2 if stereo else 1)], cfg_idx=None)
+    g, o = run_both(pkg, oracle, b, variant=variant)
+    assert (o[3] == 0).all()
+    assert_same(g, o, b["stream_cfgs"], None)
