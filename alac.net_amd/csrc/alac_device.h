@@ -75,11 +75,18 @@ __device__ __forceinline__ uint32_t peek_bits(const uint8_t* base, int64_t limit
     return (uint32_t)(w >> 32) >> (32 - nbits);
 }
 
+// ---- LDS by integer address: lets the ring wrap be one v_and_or_b32 -----------------------------------
+typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+__device__ __forceinline__ uint32_t lds_addr(const uint32_t* p) { return (uint32_t)(uintptr_t)(const lds_u32_t*)p; }
+__device__ __forceinline__ uint32_t lds_load(uint32_t a) { return *(const lds_u32_t*)(uintptr_t)a; }
+
 // ---- Rice reader state (row-uniform) -------------------------------------------------------------
 struct Rice {
     uint32_t w0, w1, w2;  // three consecutive big-endian dwords; w2 is the prefetched one
     int rem;              // unconsumed bits left in w0, 0..31
-    uint32_t next;        // byte offset (from the aligned packet base) of the dword after w2
+    uint32_t ra;          // LDS byte address of w2's dword inside the (1 KiB aligned) ring
+    uint32_t ra_sync;     // value of ra when `next` was last brought up to date (rice_sync)
+    uint32_t next;        // byte offset (from the aligned packet base) of the dword after w2; lazily updated
     int hist;             // history            (AlacFile.cs:216)
     int signmod;          // signModifier       (:218)
     int zrun;             // zeros still to emit from the last run (:238-245)
@@ -107,19 +114,25 @@ __device__ __forceinline__ uint32_t and_not(uint32_t b, uint32_t m) {  // b & ~m
 __device__ __forceinline__ uint32_t rice_window(const Rice& s) {
     return __builtin_amdgcn_alignbit(s.w0, s.w1, s.rem);
 }
-__device__ __forceinline__ void rice_advance(Rice& s, int c, const uint32_t* ring) {
+__device__ __forceinline__ void rice_advance(Rice& s, int c, uint32_t ring) {
     int rem = s.rem - c;
     bool adv = rem < 0;
     s.rem = rem & 31;
     s.w0 = adv ? s.w1 : s.w0;
     s.w1 = adv ? s.w2 : s.w1;
-    s.next += adv ? 4u : 0u;
-    s.w2 = ring[((s.next - 4u) & RING_MASK) >> 2];
+    s.ra = ((s.ra + (adv ? 4u : 0u)) & RING_MASK) | ring;   // ring base is 1 KiB aligned: one v_and_or_b32
+    s.w2 = lds_load(s.ra);
+}
+// Brings s.next up to date.  Must be called at least once per RING_BYTES of consumption (callers do it
+// every 16 samples, <= 118 bytes) and before ring_fill / rice_bitpos.
+__device__ __forceinline__ void rice_sync(Rice& s) {
+    s.next += (s.ra - s.ra_sync) & RING_MASK;
+    s.ra_sync = s.ra;
 }
 __device__ __forceinline__ uint32_t rice_bitpos(const Rice& s) { return (s.next - 12u) * 8u + 32u - (uint32_t)s.rem; }
 
 // One EntropyDecodeValue (AlacFile.cs:193-212).  m = ((1<<k)-1) & mask, escape_bits = rss or 16.
-__device__ __forceinline__ uint32_t rice_symbol(Rice& s, int k, uint32_t m, int escape_bits, const uint32_t* ring) {
+__device__ __forceinline__ uint32_t rice_symbol(Rice& s, int k, uint32_t m, int escape_bits, uint32_t ring) {
     uint32_t win = rice_window(s);
     uint32_t x = (uint32_t)__clz((int)~win);  // leading ones; 32 when win is all ones
     uint32_t v;
@@ -147,7 +160,7 @@ struct RiceCfg {
 // The "compressed blocks of 0" branch of EntropyRiceDecode (AlacFile.cs:231-249), taken right after a
 // value whose updated history fell below 128 (and a sample remains).  s.hist holds that history.
 __device__ __forceinline__ void rice_run_part(Rice& s, const RiceCfg& c, int sample_idx, int* flags,
-                                              const uint32_t* ring) {
+                                              uint32_t ring) {
     int h = s.hist;
     if (h < 0) { *flags |= 2; h = 0; }
     s.signmod = 1;                                                            // :233
@@ -164,7 +177,7 @@ __device__ __forceinline__ void rice_run_part(Rice& s, const RiceCfg& c, int sam
 // outputSize-1-outputCount.  Sets *flags bit0 when a zero run would leave the reference's 16384-entry
 // scratch, bit1 when history went negative.
 __device__ __forceinline__ int rice_step(Rice& s, const RiceCfg& c, int remaining, int sample_idx, int* flags,
-                                         const uint32_t* ring) {
+                                         uint32_t ring) {
     int r = 0;
     if (s.zrun > 0) {
         s.zrun--;
@@ -191,7 +204,7 @@ __device__ __forceinline__ int rice_step(Rice& s, const RiceCfg& c, int remainin
 // rice_step.  A lane that has left the common case keeps running on garbage; that is harmless (LDS ring
 // reads are address-masked, nothing else is touched).
 template <bool WANT_R>
-__device__ __forceinline__ int rice_spec_step(Rice& s, const RiceCfg& c, const uint32_t* ring, uint32_t& xmax,
+__device__ __forceinline__ int rice_spec_step(Rice& s, const RiceCfg& c, uint32_t ring, uint32_t& xmax,
                                               int& hmin) {
     const uint32_t win = rice_window(s);
     const uint32_t x = (uint32_t)__builtin_clz(~win | 0x00400000u);          // leading ones, capped at 9 (:196)
@@ -213,8 +226,8 @@ __device__ __forceinline__ int rice_spec_step(Rice& s, const RiceCfg& c, const u
     s.rem = rem2 & 31;
     s.w0 = adv ? s.w1 : s.w0;
     s.w1 = adv ? s.w2 : s.w1;
-    s.next += adv ? 4u : 0u;
-    s.w2 = ring[((s.next - 4u) & RING_MASK) >> 2];
+    s.ra = ((s.ra + (adv ? 4u : 0u)) & RING_MASK) | ring;
+    s.w2 = lds_load(s.ra);
     s.hist = hn;
     return r;
 }
@@ -223,7 +236,7 @@ __device__ __forceinline__ int rice_spec_step(Rice& s, const RiceCfg& c, const u
 // its next value.  Still straight-line; only a NEW run symbol (history < 128 after a value) or an escape
 // code sends the unit to rice_step.
 template <bool WANT_R>
-__device__ __forceinline__ int rice_spec_step_z(Rice& s, const RiceCfg& c, const uint32_t* ring, uint32_t& xmax,
+__device__ __forceinline__ int rice_spec_step_z(Rice& s, const RiceCfg& c, uint32_t ring, uint32_t& xmax,
                                                 int& hmin) {
     const bool inrun = s.zrun > 0;
     const uint32_t win = rice_window(s);
@@ -245,8 +258,8 @@ __device__ __forceinline__ int rice_spec_step_z(Rice& s, const RiceCfg& c, const
     s.rem = rem2 & 31;
     s.w0 = adv ? s.w1 : s.w0;
     s.w1 = adv ? s.w2 : s.w1;
-    s.next += adv ? 4u : 0u;
-    s.w2 = ring[((s.next - 4u) & RING_MASK) >> 2];
+    s.ra = ((s.ra + (adv ? 4u : 0u)) & RING_MASK) | ring;
+    s.w2 = lds_load(s.ra);
     s.hist = inrun ? h : hv;
     s.signmod = inrun ? s.signmod : 0;
     s.zrun -= inrun ? 1 : 0;
@@ -294,6 +307,8 @@ __device__ __forceinline__ void rice_init(Rice& s, uint32_t& filled, uint32_t st
     s.w0 = ring[((d) & RING_MASK) >> 2];
     s.w1 = ring[((d + 4u) & RING_MASK) >> 2];
     s.w2 = ring[((d + 8u) & RING_MASK) >> 2];
+    s.ra = lds_addr(ring) | ((d + 8u) & RING_MASK);
+    s.ra_sync = s.ra;
 }
 
 // ---- FIR state: tap j = l + 16*t lives in lane l, register t ---------------------------------------

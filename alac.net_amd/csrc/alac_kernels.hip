@@ -63,6 +63,9 @@ __device__ void decode_wave(const alac_decode_params& p, const Meta& m, const al
     rc.rss = m.rss;
 
     Rice rs;
+    rs.w0 = rs.w1 = rs.w2 = 0; rs.rem = 0; rs.next = 12; rs.hist = 0; rs.signmod = 0; rs.zrun = 0; rs.nforce = 0;
+    const uint32_t ringa = lds_addr(ring);
+    rs.ra = rs.ra_sync = ringa;
     uint32_t filled = 0;
 
     // ---- pre-scan: Rice-only pass over channel A of stereo packets to find where B starts ----
@@ -75,13 +78,15 @@ __device__ void decode_wave(const alac_decode_params& p, const Meta& m, const al
         rice_init<16>(rs, filled, m.ricebit, cfg.rice_initial_history, ring, m.base, m.limit, l, pre_on);
         int dummy = 0;
         for (int i = 0; i < npre_max; i++) {
-            if (i < n_pre) (void)rice_step(rs, rc, n_pre - 1 - i, i, &dummy, ring);
+            if (i < n_pre) (void)rice_step(rs, rc, n_pre - 1 - i, i, &dummy, ringa);
             if ((i & 15) == 15) {
                 wave_sync();
+                rice_sync(rs);
                 ring_fill<16>(ring, filled, rs.next, m.base, m.limit, l, pre_on);
                 wave_sync();
             }
         }
+        rice_sync(rs);
         bstart = rice_bitpos(rs);
     }
     uint32_t other = (uint32_t)__shfl((int)bstart, lane ^ 16, 64);
@@ -115,12 +120,13 @@ __device__ void decode_wave(const alac_decode_params& p, const Meta& m, const al
             for (int ii = 0; ii < iend; ii++) {
                 int i = i0 + ii;
                 if (i < n_row) {
-                    int err = rice_step(rs, rc, n_row - 1 - i, i, &flags, ring);
+                    int err = rice_step(rs, rc, n_row - 1 - i, i, &flags, ringa);
                     int out = fir_step<TPL>(f, err, i, m.N, m.q, m.rnd, m.rss, l, rowlane0);
                     cap = (l == ii) ? out : cap;
                 }
             }
             wave_sync();
+            rice_sync(rs);
             ring_fill<16>(ring, filled, rs.next, m.base, m.limit, l, stream_on && i0 + 16 < n_row);
             wave_sync();
         }
@@ -163,6 +169,7 @@ __device__ void decode_wave(const alac_decode_params& p, const Meta& m, const al
     }
 
     // ---- status: same priority order as the oracle / the reference's control flow ----
+    rice_sync(rs);
     int fl_other = __shfl(flags, lane ^ 16, 64);
     int pt_other = __shfl(m.predtype, lane ^ 16, 64);
     int N_other = __shfl(m.N, lane ^ 16, 64);
@@ -194,7 +201,7 @@ __device__ void decode_wave(const alac_decode_params& p, const Meta& m, const al
 }  // namespace
 
 extern "C" __global__ __launch_bounds__(64) void alac_decode_packets_kernel(alac_decode_params p) {
-    __shared__ __attribute__((aligned(16))) uint32_t ring_all[4][RING_BYTES / 4];
+    __shared__ __attribute__((aligned(1024))) uint32_t ring_all[4][RING_BYTES / 4];
     const int lane = threadIdx.x;
     const int row = lane >> 4, l = lane & 15, chan = row & 1;
     const uint32_t pkt = blockIdx.x * 2u + (uint32_t)(row >> 1);
@@ -287,6 +294,7 @@ __device__ void entropy_wave(const alac_decode_params& p, uint32_t pkt0, int lan
 
     Rice rs;
     rs.w0 = rs.w1 = rs.w2 = 0; rs.rem = 0; rs.next = 12; rs.hist = 0; rs.signmod = 0; rs.zrun = 0; rs.nforce = 0;
+    rs.ra = rs.ra_sync = lds_addr(sh.rings[g]);
     uint32_t filled = 0;
     if (p.dbg && lane == 0) p.dbg[8 * blockIdx.x + 0] = clock64();
 
@@ -307,16 +315,18 @@ __device__ void entropy_wave(const alac_decode_params& p, uint32_t pkt0, int lan
             const int n_eff = mirror_i(m.n, src);
             const int ih = mirror_i(init_hist, src);
             const uint32_t sb = (uint32_t)mirror_i((int)m.ricebit, src);
-            const uint32_t* pring = sh.rings[mirror_i(g, src)];
+            const uint32_t* pringp = sh.rings[mirror_i(g, src)];
+            const uint32_t pring = lds_addr(pringp);
             const int nmin = __builtin_amdgcn_readfirstlane(-wave_max(-n_eff));
             const int nmax = __builtin_amdgcn_readfirstlane(wave_max(pre_on ? m.n : 0));
             rice_init<LPS>(rs, filled, sb, ih, sh.rings[g], m.base, m.limit, sub, pre_on);
             // the shadows read the donor's ring: reload their window from it
             if (!pre_on) {
                 const uint32_t d0 = rs.next - 12u;
-                rs.w0 = pring[(d0 & RING_MASK) >> 2];
-                rs.w1 = pring[((d0 + 4u) & RING_MASK) >> 2];
-                rs.w2 = pring[((d0 + 8u) & RING_MASK) >> 2];
+                rs.w0 = pringp[(d0 & RING_MASK) >> 2];
+                rs.w1 = pringp[((d0 + 4u) & RING_MASK) >> 2];
+                rs.w2 = pringp[((d0 + 8u) & RING_MASK) >> 2];
+                rs.ra = rs.ra_sync = pring | ((d0 + 8u) & RING_MASK);
             }
             int dummy = 0;
             int i = 0;
@@ -347,6 +357,7 @@ __device__ void entropy_wave(const alac_decode_params& p, uint32_t pkt0, int lan
                     }
                 }
                 wave_sync();
+                rice_sync(rs);
                 ring_fill<LPS>(sh.rings[g], filled, rs.next, m.base, m.limit, sub, pre_on);
                 wave_sync();
             }
@@ -354,10 +365,12 @@ __device__ void entropy_wave(const alac_decode_params& p, uint32_t pkt0, int lan
                 if (pre_on && i < m.n) (void)rice_step(rs, pc, m.n - 1 - i, i, &dummy, pring);
                 if ((i & 15) == 15) {
                     wave_sync();
+                    rice_sync(rs);
                     ring_fill<LPS>(sh.rings[g], filled, rs.next, m.base, m.limit, sub, pre_on && i + 1 < m.n);
                     wave_sync();
                 }
             }
+            rice_sync(rs);
             bstart = rice_bitpos(rs);
         }
     }
@@ -376,16 +389,18 @@ __device__ void entropy_wave(const alac_decode_params& p, uint32_t pkt0, int lan
     const int n_eff = mirror_i(m.n, src);
     const int ih = mirror_i(init_hist, src);
     const uint32_t sb = (uint32_t)mirror_i((int)startbit, src);
-    const uint32_t* mring = sh.rings[mirror_i(g, src)];
+    const uint32_t* mringp = sh.rings[mirror_i(g, src)];
+    const uint32_t mring = lds_addr(mringp);
     const int nmin = onmask ? __builtin_amdgcn_readfirstlane(-wave_max(-n_eff)) : 0;
     const int nmax = __builtin_amdgcn_readfirstlane(wave_max(n_row));
     if (nmax > 0) {
         rice_init<LPS>(rs, filled, sb, ih, sh.rings[g], m.base, m.limit, sub, stream_on);
         if (!stream_on) {
             const uint32_t d0 = rs.next - 12u;
-            rs.w0 = mring[(d0 & RING_MASK) >> 2];
-            rs.w1 = mring[((d0 + 4u) & RING_MASK) >> 2];
-            rs.w2 = mring[((d0 + 8u) & RING_MASK) >> 2];
+            rs.w0 = mringp[(d0 & RING_MASK) >> 2];
+            rs.w1 = mringp[((d0 + 4u) & RING_MASK) >> 2];
+            rs.w2 = mringp[((d0 + 8u) & RING_MASK) >> 2];
+            rs.ra = rs.ra_sync = mring | ((d0 + 8u) & RING_MASK);
         }
     }
 
@@ -435,6 +450,7 @@ __device__ void entropy_wave(const alac_decode_params& p, uint32_t pkt0, int lan
                 }
             }
             wave_sync();
+            rice_sync(rs);
             ring_fill<LPS>(sh.rings[g], filled, rs.next, m.base, m.limit, sub, stream_on && i0 + CHUNK < n_row);
         }
         const unsigned long long tb = p.dbg ? clock64() : 0;
@@ -449,6 +465,7 @@ __device__ void entropy_wave(const alac_decode_params& p, uint32_t pkt0, int lan
     if (p.dbg && lane == 0) p.dbg[8 * blockIdx.x + 2] = clock64();
 
     // ---- status, in the reference's control-flow order (same as v1 / the oracle) ----
+    rice_sync(rs);
     const int fl_other = __shfl(flags, lane ^ LPS, 64);
     const int pt_other = __shfl(m.predtype, lane ^ LPS, 64);
     const int N_other = __shfl(m.N, lane ^ LPS, 64);
@@ -767,7 +784,7 @@ __device__ void recon_wave(const alac_decode_params& p, uint32_t pkt0, int w, in
 
 template <int F>
 __device__ __forceinline__ void split_kernel_body(const alac_decode_params& p) {
-    __shared__ __attribute__((aligned(16))) SplitShared<F> sh;
+    __shared__ __attribute__((aligned(1024))) SplitShared<F> sh;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t pkt0 = blockIdx.x * (uint32_t)(2 * F);
     // chunk count must be uniform over the workgroup: every wave derives it from all 2F headers
