@@ -267,12 +267,17 @@ __device__ __forceinline__ T wave_max(T v) {
 // value of `v` in lane `src` (a lane mirrors itself when src == its own id)
 __device__ __forceinline__ int mirror_i(int v, int src) { return __shfl(v, src, 64); }
 
-template <int F>
+// MONO (every stream cfg of the context has one channel): a stream IS a packet -- no B channel, no
+// pre-scan, twice as many packets per workgroup.
+template <bool MONO> __device__ __forceinline__ int stream_packet(int g) { return MONO ? g : (g >> 1); }
+template <bool MONO> __device__ __forceinline__ int stream_chan(int g) { return MONO ? 0 : (g & 1); }
+
+template <int F, bool MONO>
 __device__ void entropy_wave(const alac_decode_params& p, uint32_t pkt0, int lane, SplitShared<F>& sh, int nchunks) {
     constexpr int S = 4 * F, LPS = 64 / S;
     const int g = lane / LPS, sub = lane % LPS;
-    const int chan = g & 1;
-    const uint32_t pkt = pkt0 + (uint32_t)(g >> 1);
+    const int chan = stream_chan<MONO>(g);
+    const uint32_t pkt = pkt0 + (uint32_t)stream_packet<MONO>(g);
     const bool valid = pkt < p.n_packets;
     alacgpu_cfg_dev cfg;
     const Meta m = parse_meta(p, pkt, chan, valid, cfg);
@@ -537,10 +542,10 @@ __device__ __forceinline__ void recon_output(const alac_decode_params& p, const 
 }
 
 template <int F, int TPL>
-__device__ void recon_wave_impl(const alac_decode_params& p, const Meta& m, bool valid, int g, int lane,
+__device__ void recon_wave_impl(const alac_decode_params& p, const Meta& m, bool valid, int g, int chan, int lane,
                                 SplitShared<F>& sh, int nchunks, uint32_t pkt) {
     constexpr int S = 4 * F;
-    const int l = lane & 15, chan = g & 1;
+    const int l = lane & 15;
     const int rowlane0 = lane & 48;
     const bool compressed = valid && m.status == 0 && !m.esc;
     const bool stream_on = compressed && (chan == 0 || m.stereo);
@@ -631,13 +636,14 @@ __device__ void recon_wave_impl(const alac_decode_params& p, const Meta& m, bool
 }
 
 // Reconstruction wave in the P8 layout (see alac_device.h): 8 streams = 4 packets per wave.
-template <int F>
+template <int F, bool MONO>
 __device__ void recon8_wave(const alac_decode_params& p, uint32_t pkt0, int w8, int lane, SplitShared<F>& sh, int nchunks,
                             bool narrow) {
     constexpr int S = 4 * F;
-    const int row = lane >> 4, l = lane & 15, chan = l & 1, j = l >> 1;
-    const int g = 8 * w8 + 2 * row + chan;                 // stream index inside the workgroup
-    const uint32_t pkt = pkt0 + (uint32_t)(g >> 1);
+    const int row = lane >> 4, l = lane & 15, par = l & 1, j = l >> 1;
+    const int g = 8 * w8 + 2 * row + par;                  // stream index inside the workgroup
+    const int chan = stream_chan<MONO>(g);
+    const uint32_t pkt = pkt0 + (uint32_t)stream_packet<MONO>(g);
     const bool valid = pkt < p.n_packets;
     alacgpu_cfg_dev cfg;
     const Meta m = parse_meta(p, pkt, chan, valid, cfg);
@@ -661,7 +667,7 @@ __device__ void recon8_wave(const alac_decode_params& p, uint32_t pkt0, int w8, 
     f.tlo = tap ? -1 : 0;
     f.thi = tap ? 1 : 0;
     f.w = tap ? (uint32_t)(m.N - j) : 0u;
-    f.bpaddr = ((lane & 48) + 2 * (stream_on ? (m.N - 1) & 7 : 0) + chan) * 4;
+    f.bpaddr = ((lane & 48) + 2 * (stream_on ? (m.N - 1) & 7 : 0) + par) * 4;
 
     const int nmax = __builtin_amdgcn_readfirstlane(wave_max(n_row));
     const int nmin = __builtin_amdgcn_readfirstlane(-wave_max(stream_on ? -m.n : -0x7FFFFFFF));
@@ -741,7 +747,7 @@ __device__ void recon8_wave(const alac_decode_params& p, uint32_t pkt0, int w8, 
     }
 }
 
-template <int F>
+template <int F, bool MONO>
 __device__ void recon_wave(const alac_decode_params& p, uint32_t pkt0, int w, int lane, SplitShared<F>& sh, int nchunks) {
     // ---- can the whole workgroup use the P8 layout?  Every wave evaluates all 4F streams the same way. ----
     bool p8 = true, narrow8 = true;
@@ -750,11 +756,12 @@ __device__ void recon_wave(const alac_decode_params& p, uint32_t pkt0, int w, in
 #pragma unroll
         for (int base = 0; base < S; base += 64) {
             const int gg = base + (lane % S);
-            const uint32_t pk = pkt0 + (uint32_t)(gg >> 1);
+            const uint32_t pk = pkt0 + (uint32_t)stream_packet<MONO>(gg);
             const bool v = pk < p.n_packets;
+            const int gc = stream_chan<MONO>(gg);
             alacgpu_cfg_dev c;
-            const Meta mm = parse_meta(p, pk, gg & 1, v, c);
-            const bool on = v && mm.status == 0 && !mm.esc && ((gg & 1) == 0 || mm.stereo);
+            const Meta mm = parse_meta(p, pk, gc, v, c);
+            const bool on = v && mm.status == 0 && !mm.esc && (gc == 0 || mm.stereo);
             const bool bad = on && (mm.N < 1 || mm.N > 8);
             if (__builtin_amdgcn_ballot_w64(bad)) p8 = false;
             if (__builtin_amdgcn_ballot_w64(on && mm.rss > 17)) narrow8 = false;
@@ -762,7 +769,7 @@ __device__ void recon_wave(const alac_decode_params& p, uint32_t pkt0, int w, in
     }
     if (p8 && F >= 2) {
         if (w < F / 2) {
-            recon8_wave<F>(p, pkt0, w, lane, sh, nchunks, narrow8);
+            recon8_wave<F, MONO>(p, pkt0, w, lane, sh, nchunks, narrow8);
         } else {
             for (int c = 0; c < nchunks; c++) wg_sync();   // nothing to do: keep the barrier count
         }
@@ -770,27 +777,28 @@ __device__ void recon_wave(const alac_decode_params& p, uint32_t pkt0, int w, in
     }
     const int row = lane >> 4;
     const int g = 4 * w + row;
-    const int chan = g & 1;
-    const uint32_t pkt = pkt0 + (uint32_t)(g >> 1);
+    const int chan = stream_chan<MONO>(g);
+    const uint32_t pkt = pkt0 + (uint32_t)stream_packet<MONO>(g);
     const bool valid = pkt < p.n_packets;
     alacgpu_cfg_dev cfg;
     const Meta m = parse_meta(p, pkt, chan, valid, cfg);
     const bool wide = valid && m.status == 0 && !m.esc && m.N > 16 && m.N <= 30 && (chan == 0 || m.stereo);
     if (__builtin_amdgcn_ballot_w64(wide))
-        recon_wave_impl<F, 2>(p, m, valid, g, lane, sh, nchunks, pkt);
+        recon_wave_impl<F, 2>(p, m, valid, g, chan, lane, sh, nchunks, pkt);
     else
-        recon_wave_impl<F, 1>(p, m, valid, g, lane, sh, nchunks, pkt);
+        recon_wave_impl<F, 1>(p, m, valid, g, chan, lane, sh, nchunks, pkt);
 }
 
-template <int F>
+template <int F, bool MONO>
 __device__ __forceinline__ void split_kernel_body(const alac_decode_params& p) {
     __shared__ __attribute__((aligned(1024))) SplitShared<F> sh;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t pkt0 = blockIdx.x * (uint32_t)(2 * F);
+    constexpr int PPW = MONO ? 4 * F : 2 * F;              // packets per workgroup
+    const uint32_t pkt0 = blockIdx.x * (uint32_t)PPW;
     // chunk count must be uniform over the workgroup: every wave derives it from all 2F headers
     int n_any = 0;
     {
-        const uint32_t pk = pkt0 + (uint32_t)(lane % (2 * F));
+        const uint32_t pk = pkt0 + (uint32_t)(lane % PPW);
         const bool v = pk < p.n_packets;
         alacgpu_cfg_dev c;
         const Meta mm = parse_meta(p, pk, 0, v, c);
@@ -803,15 +811,18 @@ __device__ __forceinline__ void split_kernel_body(const alac_decode_params& p) {
     if (wave == 0) {
         // the entropy wave is the longest dependent chain of the workgroup: let it win issue arbitration
         __builtin_amdgcn_s_setprio(ALAC_ENTROPY_PRIO);
-        entropy_wave<F>(p, pkt0, lane, sh, nchunks);
+        entropy_wave<F, MONO>(p, pkt0, lane, sh, nchunks);
     }
     else {
-        recon_wave<F>(p, pkt0, wave - 1, lane, sh, nchunks);
+        recon_wave<F, MONO>(p, pkt0, wave - 1, lane, sh, nchunks);
     }
 }
 
 }  // namespace
 
-extern "C" __global__ __launch_bounds__(128) void alac_decode_split1_kernel(alac_decode_params p) { split_kernel_body<1>(p); }
-extern "C" __global__ __launch_bounds__(192) void alac_decode_split2_kernel(alac_decode_params p) { split_kernel_body<2>(p); }
-extern "C" __global__ __launch_bounds__(320) void alac_decode_split4_kernel(alac_decode_params p) { split_kernel_body<4>(p); }
+extern "C" __global__ __launch_bounds__(128) void alac_decode_split1_kernel(alac_decode_params p) { split_kernel_body<1, false>(p); }
+extern "C" __global__ __launch_bounds__(192) void alac_decode_split2_kernel(alac_decode_params p) { split_kernel_body<2, false>(p); }
+extern "C" __global__ __launch_bounds__(320) void alac_decode_split4_kernel(alac_decode_params p) { split_kernel_body<4, false>(p); }
+// one-channel streams: 8 / 16 packets per workgroup, no pre-scan
+extern "C" __global__ __launch_bounds__(192) void alac_decode_split2_mono_kernel(alac_decode_params p) { split_kernel_body<2, true>(p); }
+extern "C" __global__ __launch_bounds__(320) void alac_decode_split4_mono_kernel(alac_decode_params p) { split_kernel_body<4, true>(p); }

@@ -22,6 +22,7 @@ struct alacgpu_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     uint32_t out_format = 0;           // 0 int32 per sample, 1 packed little-endian PCM
+    bool all_mono = false;             // every stream cfg has one channel -> the *_mono kernels
     int variant = 0;                   // 0 auto, 1 fused (v1), 2/3/4 split with 1/2/4 reconstruction waves
     // grow-only device workspace for the host-buffer entry points
     void* d_ws = nullptr;
@@ -61,7 +62,7 @@ int launch(alacgpu_ctx* ctx, const alac_decode_params& p, hipStream_t stream) {
     // auto: up to ~4 workgroups per CU the 4-packet workgroup (1 entropy + 2 reconstruction waves) has the
     // shortest critical path; bigger batches are throughput bound and do better with 8 packets per workgroup
     // (half as many entropy waves).  Measured on MI355X: cfg2 (4096 packets) 1.43 vs 1.51 ms, cfg3 (8192) 9.4 vs 7.0 ms.
-    if (variant == 0) variant = p.n_packets >= 6144 ? 4 : 3;
+    if (variant == 0) variant = p.n_packets >= (ctx->all_mono ? 12288u : 6144u) ? 4 : 3;
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
     switch (variant) {
     case 1:
@@ -71,10 +72,16 @@ int launch(alacgpu_ctx* ctx, const alac_decode_params& p, hipStream_t stream) {
         hipLaunchKernelGGL(alac_decode_split1_kernel, dim3((p.n_packets + 1) / 2), dim3(128), 0, stream, p);
         break;
     case 4:
-        hipLaunchKernelGGL(alac_decode_split4_kernel, dim3((p.n_packets + 7) / 8), dim3(320), 0, stream, p);
+        if (ctx->all_mono)
+            hipLaunchKernelGGL(alac_decode_split4_mono_kernel, dim3((p.n_packets + 15) / 16), dim3(320), 0, stream, p);
+        else
+            hipLaunchKernelGGL(alac_decode_split4_kernel, dim3((p.n_packets + 7) / 8), dim3(320), 0, stream, p);
         break;
     default:
-        hipLaunchKernelGGL(alac_decode_split2_kernel, dim3((p.n_packets + 3) / 4), dim3(192), 0, stream, p);
+        if (ctx->all_mono)
+            hipLaunchKernelGGL(alac_decode_split2_mono_kernel, dim3((p.n_packets + 7) / 8), dim3(192), 0, stream, p);
+        else
+            hipLaunchKernelGGL(alac_decode_split2_kernel, dim3((p.n_packets + 3) / 4), dim3(192), 0, stream, p);
         break;
     }
     HIP_TRY(ctx, hipGetLastError());
@@ -148,6 +155,8 @@ int alacgpu_create(const alacgpu_cfg* cfgs, uint32_t n_cfgs, int device, alacgpu
     if (!ctx) return ALACGPU_ERR_NO_MEMORY;
     ctx->device = device;
     ctx->n_cfgs = n_cfgs;
+    ctx->all_mono = true;
+    for (uint32_t i = 0; i < n_cfgs; i++) ctx->all_mono = ctx->all_mono && cfgs[i].num_channels == 1;
     if (const char* v = std::getenv("ALACGPU_KERNEL_VARIANT")) ctx->variant = std::atoi(v) >= 0 && std::atoi(v) <= 4 ? std::atoi(v) : 0;
     int rc = ALACGPU_OK;
     do {
