@@ -61,8 +61,9 @@ int launch(alacgpu_ctx* ctx, const alac_decode_params& p, hipStream_t stream) {
     int variant = ctx->variant;
     // auto: up to ~4 workgroups per CU the 4-packet workgroup (1 entropy + 2 reconstruction waves) has the
     // shortest critical path; bigger batches are throughput bound and do better with 8 packets per workgroup
-    // (half as many entropy waves).  Measured on MI355X: cfg2 (4096 packets) 1.43 vs 1.51 ms, cfg3 (8192) 9.4 vs 7.0 ms.
-    if (variant == 0) variant = p.n_packets >= (ctx->all_mono ? 12288u : 6144u) ? 4 : 3;
+    // (a quarter as many entropy waves).  Measured on MI355X: cfg2 (4096 packets) 1.27 / 1.33 / 1.42 ms for 4 / 8 / 16
+    // packets per workgroup, cfg3 (8192 packets) 8.5 / 7.1 / 6.9 ms.
+    if (variant == 0) variant = p.n_packets >= (ctx->all_mono ? 12288u : 6144u) ? (ctx->all_mono ? 4 : 5) : 3;
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
     switch (variant) {
     case 1:
@@ -70,6 +71,9 @@ int launch(alacgpu_ctx* ctx, const alac_decode_params& p, hipStream_t stream) {
         break;
     case 2:
         hipLaunchKernelGGL(alac_decode_split1_kernel, dim3((p.n_packets + 1) / 2), dim3(128), 0, stream, p);
+        break;
+    case 5:
+        hipLaunchKernelGGL(alac_decode_split8_kernel, dim3((p.n_packets + 15) / 16), dim3(576), 0, stream, p);
         break;
     case 4:
         if (ctx->all_mono)
@@ -157,7 +161,7 @@ int alacgpu_create(const alacgpu_cfg* cfgs, uint32_t n_cfgs, int device, alacgpu
     ctx->n_cfgs = n_cfgs;
     ctx->all_mono = true;
     for (uint32_t i = 0; i < n_cfgs; i++) ctx->all_mono = ctx->all_mono && cfgs[i].num_channels == 1;
-    if (const char* v = std::getenv("ALACGPU_KERNEL_VARIANT")) ctx->variant = std::atoi(v) >= 0 && std::atoi(v) <= 4 ? std::atoi(v) : 0;
+    if (const char* v = std::getenv("ALACGPU_KERNEL_VARIANT")) ctx->variant = std::atoi(v) >= 0 && std::atoi(v) <= 5 ? std::atoi(v) : 0;
     int rc = ALACGPU_OK;
     do {
         if (hipSetDevice(device) != hipSuccess) { rc = ALACGPU_ERR_NO_DEVICE; break; }
@@ -352,7 +356,7 @@ int alacgpu_set_output_format(alacgpu_ctx* ctx, int format) {
 }
 
 int alacgpu_set_kernel_variant(alacgpu_ctx* ctx, int variant) {
-    if (!ctx || variant < 0 || variant > 4) return ALACGPU_ERR_BAD_ARG;
+    if (!ctx || variant < 0 || variant > 5) return ALACGPU_ERR_BAD_ARG;
     ctx->variant = variant;
     return ALACGPU_OK;
 }
