@@ -265,6 +265,51 @@ __device__ __forceinline__ int rice_spec_step_z(Rice& s, const RiceCfg& c, uint3
     s.zrun -= inrun ? 1 : 0;
     return r;
 }
+// Full-featured speculative step: additionally handles, still as straight-line code,
+//   * lanes inside a zero run / with signModifier pending (digital silence): emit 0 without touching the
+//     bitstream while zrun > 0, add signModifier to the next value;
+//   * escape codes (nine 1s + rss raw bits, AlacFile.cs:198-202): loud / noisy content, where the history
+//     clamp (:229) keeps k small and escapes are frequent.  An escape consumes up to 9 + 25 bits, so the
+//     window slides by 0, 1 or 2 dwords per step and a fourth dword (w3) is kept prefetched.
+// Only a NEW run symbol (history < 128 after a value) sends the unit to rice_step.
+template <bool WANT_R>
+__device__ __forceinline__ int rice_spec_step_full(Rice& s, uint32_t& w3, const RiceCfg& c, uint32_t ring, uint32_t& xmax,
+                                                   int& hmin) {
+    const bool inrun = s.zrun > 0;
+    const uint32_t win = rice_window(s);
+    const uint32_t win2 = __builtin_amdgcn_alignbit(s.w1, s.w2, s.rem);      // the 32 bits after `win`
+    const uint32_t x = (uint32_t)__builtin_clz(~win | 0x00400000u);
+    const bool esc = x > 8u;
+    xmax = max(xmax, inrun ? 0u : x);
+    const int k = min(22 - __builtin_clz((uint32_t)(s.hist + 1536)), c.kmod);
+    const uint32_t e = __builtin_amdgcn_ubfe(win, (uint32_t)(31 - k) - x, (uint32_t)k);
+    const uint32_t m = __builtin_amdgcn_ubfe(0xFFFFFFFFu, 0u, (uint32_t)k);
+    const uint32_t vn = __umul24(x, m) + (e > 1u ? e - 1u : 0u);
+    const uint32_t raw = __builtin_amdgcn_alignbit(win, win2, 23) >> (32 - c.rss);   // bits 9 .. 9+rss of the stream
+    const uint32_t v = (esc ? raw : vn) + (uint32_t)s.signmod;                        // :224
+    const int used = esc ? 9 + c.rss : (int)(x + (uint32_t)k) + (e > 1u ? 1 : 0);
+    const int rem2 = inrun ? s.rem : s.rem - used;                            // >= -34
+    int r = 0;
+    if (WANT_R) r = inrun ? 0 : (int)(v >> 1) ^ -(int)(v & 1u);
+    const int h = s.hist;
+    int hx = (int)(__umul24(v, (uint32_t)c.hist_mult) + (uint32_t)h) - (wmul(h, c.hist_mult) >> 9);
+    asm volatile("" : "+v"(hx));
+    const int hv = (int)v > 0xFFFF ? 0xFFFF : hx;                             // :229 (hx is unused garbage when v is huge)
+    hmin = min(hmin, inrun ? 0x7FFFFFFF : hv);
+    const bool a1 = rem2 < 0, a2 = rem2 < -32;
+    s.rem = rem2 & 31;
+    const uint32_t n0 = a2 ? s.w2 : (a1 ? s.w1 : s.w0);
+    const uint32_t n1 = a2 ? w3 : (a1 ? s.w2 : s.w1);
+    s.w0 = n0;
+    s.w1 = n1;
+    s.ra = ((s.ra + (a2 ? 8u : (a1 ? 4u : 0u))) & RING_MASK) | ring;
+    s.w2 = lds_load(s.ra);
+    w3 = lds_load(((s.ra + 4u) & RING_MASK) | ring);
+    s.hist = inrun ? h : hv;
+    s.signmod = inrun ? s.signmod : 0;
+    s.zrun -= inrun ? 1 : 0;
+    return r;
+}
 constexpr int SPEC_UNIT = 4;   // steps per speculative unit
 
 // ---- per-row LDS ring ------------------------------------------------------------------------------

@@ -264,6 +264,62 @@ __device__ __forceinline__ T wave_max(T v) {
     return v;
 }
 
+// One speculative unit (SPEC_UNIT samples) of the entropy wave.  Tiers, cheapest first:
+//   1  rice_spec_step       plain values only
+//   2  rice_spec_step_z     + zero runs in progress / signModifier pending   (digital silence)
+//   3  rice_spec_step_full  + escape codes                                   (loud / noisy content)
+// A unit whose lanes met something its tier cannot do is restored from its snapshot and retried higher; a NEW run
+// symbol (history < 128 after a value) is beyond all tiers: the function then returns false with the state
+// restored, and the caller decodes the unit with rice_step.  After an escape was seen the wave stays on tier 3 for
+// FULL_HOLD clean units (escapes come in stretches, and a failed cheaper attempt costs a whole unit).
+constexpr int FULL_HOLD = 4;
+
+template <bool WANT_R, int QSTRIDE>
+__device__ __forceinline__ bool spec_unit(Rice& rs, int& full_left, const RiceCfg& c, uint32_t ring, int* q) {
+    const Rice snap = rs;
+    const bool special = __builtin_amdgcn_ballot_w64(rs.nforce == 0u) != 0;
+    uint32_t xmax = 0;
+    int hmin = 0x7FFFFFFF;
+    if (full_left == 0) {
+        if (!special) {
+#pragma unroll
+            for (int ii = 0; ii < SPEC_UNIT; ii++) {
+                const int r = rice_spec_step<WANT_R>(rs, c, ring, xmax, hmin);
+                if (WANT_R) q[ii * QSTRIDE] = r;
+            }
+        } else {
+#pragma unroll
+            for (int ii = 0; ii < SPEC_UNIT; ii++) {
+                const int r = rice_spec_step_z<WANT_R>(rs, c, ring, xmax, hmin);
+                if (WANT_R) q[ii * QSTRIDE] = r;
+            }
+            rs.nforce = (rs.zrun > 0 || rs.signmod != 0) ? 0u : 0xFFFFFFFFu;
+        }
+        const bool newrun = __builtin_amdgcn_ballot_w64(hmin < 128) != 0;
+        const bool sawesc = __builtin_amdgcn_ballot_w64(xmax > 8u) != 0;
+        if (__builtin_expect(!newrun && !sawesc, 1)) return true;
+        rs = snap;
+        if (newrun) return false;          // no tier can do it
+        full_left = FULL_HOLD;             // escapes: go on with tier 3
+        xmax = 0;
+        hmin = 0x7FFFFFFF;
+    }
+    uint32_t w3 = lds_load(((rs.ra + 4u) & RING_MASK) | ring);
+#pragma unroll
+    for (int ii = 0; ii < SPEC_UNIT; ii++) {
+        const int r = rice_spec_step_full<WANT_R>(rs, w3, c, ring, xmax, hmin);
+        if (WANT_R) q[ii * QSTRIDE] = r;
+    }
+    rs.nforce = (rs.zrun > 0 || rs.signmod != 0) ? 0u : 0xFFFFFFFFu;
+    const bool sawesc = __builtin_amdgcn_ballot_w64(xmax > 8u) != 0;
+    full_left = sawesc ? FULL_HOLD : full_left - 1;
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(hmin < 128) != 0, 0)) {
+        rs = snap;
+        return false;
+    }
+    return true;
+}
+
 // value of `v` in lane `src` (a lane mirrors itself when src == its own id)
 __device__ __forceinline__ int mirror_i(int v, int src) { return __shfl(v, src, 64); }
 
@@ -297,6 +353,7 @@ __device__ void entropy_wave(const alac_decode_params& p, uint32_t pkt0, int lan
     rc.rss = m.rss;
     int init_hist = cfg.rice_initial_history;
 
+    int full_left = 0;   // > 0: stay on the escape-capable speculative tier (see spec_unit)
     Rice rs;
     rs.w0 = rs.w1 = rs.w2 = 0; rs.rem = 0; rs.next = 12; rs.hist = 0; rs.signmod = 0; rs.zrun = 0; rs.nforce = 0;
     rs.ra = rs.ra_sync = lds_addr(sh.rings[g]);
@@ -337,25 +394,7 @@ __device__ void entropy_wave(const alac_decode_params& p, uint32_t pkt0, int lan
             int i = 0;
             for (; i + CHUNK <= nmin - 1; i += CHUNK) {   // every lane has a sample left after each of these
                 for (int u = 0; u < CHUNK; u += SPEC_UNIT) {
-                    bool redo = false;
-                    {
-                        const bool special = __builtin_amdgcn_ballot_w64(rs.nforce == 0u) != 0;
-                        const Rice snap = rs;
-                        uint32_t xmax = 0;
-                        int hmin = 0x7FFFFFFF;
-                        if (!special) {
-#pragma unroll
-                            for (int ii = 0; ii < SPEC_UNIT; ii++) (void)rice_spec_step<false>(rs, pc, pring, xmax, hmin);
-                        } else {
-#pragma unroll
-                            for (int ii = 0; ii < SPEC_UNIT; ii++) (void)rice_spec_step_z<false>(rs, pc, pring, xmax, hmin);
-                            rs.nforce = (rs.zrun > 0 || rs.signmod != 0) ? 0u : 0xFFFFFFFFu;
-                        }
-                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(xmax > 8u || hmin < 128) != 0, 0)) {
-                            rs = snap;
-                            redo = true;
-                        }
-                    }
+                    const bool redo = !spec_unit<false, 0>(rs, full_left, pc, pring, nullptr);
                     if (redo) {
                         for (int ii = 0; ii < SPEC_UNIT; ii++)
                             (void)rice_step(rs, pc, n_eff - 1 - (i + u + ii), i + u + ii, &dummy, pring);
@@ -418,27 +457,7 @@ __device__ void entropy_wave(const alac_decode_params& p, uint32_t pkt0, int lan
         if (i0 < nmax) {
             if (i0 + CHUNK <= nmin - 1) {                  // fast chunk: all lanes decode, a sample always remains
                 for (int u = 0; u < CHUNK; u += SPEC_UNIT) {
-                    bool redo = false;
-                    {
-                        const bool special = __builtin_amdgcn_ballot_w64(rs.nforce == 0u) != 0;
-                        const Rice snap = rs;
-                        uint32_t xmax = 0;
-                        int hmin = 0x7FFFFFFF;
-                        if (!special) {
-#pragma unroll
-                            for (int ii = 0; ii < SPEC_UNIT; ii++)
-                                q[(u + ii) * S] = rice_spec_step<true>(rs, mc, mring, xmax, hmin);
-                        } else {   // some lane is inside a zero run: the run-aware straight-line step
-#pragma unroll
-                            for (int ii = 0; ii < SPEC_UNIT; ii++)
-                                q[(u + ii) * S] = rice_spec_step_z<true>(rs, mc, mring, xmax, hmin);
-                            rs.nforce = (rs.zrun > 0 || rs.signmod != 0) ? 0u : 0xFFFFFFFFu;
-                        }
-                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(xmax > 8u || hmin < 128) != 0, 0)) {
-                            rs = snap;
-                            redo = true;
-                        }
-                    }
+                    const bool redo = !spec_unit<true, S>(rs, full_left, mc, mring, q + u * S);
                     if (redo) nredo++;
                     if (redo) {   // some lane met an escape / a zero run: decode this unit with the full step
                         for (int ii = 0; ii < SPEC_UNIT; ii++)
