@@ -481,6 +481,56 @@ __device__ __forceinline__ void fir_fast(FirLane& f, int err) {
     f.base = nb;
 }
 
+// ---- FIR fast step, two tap registers per lane ------------------------------------------------------
+// Steady state for waves in which some stream has more than 16 taps: tap j = l + 16t in lane l, register t.
+// Rows with N <= 16 simply leave register 1 empty (coef = w = 0).  Rows with N == 31 are in the reference's
+// first-order "delta" mode (AlacFile.cs:268-282): they carry no taps at all (coef = w = 0, sign bounds 0) and take
+// out = sx(prev + err).  Taps are visited from 31 down to 0, so register 1's total decrement comes on top of
+// register 0's suffix sums.
+struct FirLane2 {
+    int hist[2], coef[2], base, prev;
+    int q, rnd, rss, qmask;
+    uint32_t w[2];
+    int tlo[2], thi[2];
+    int bpaddr;
+    bool bphi;     // tap N-1 lives in register 1
+    bool delta;    // N == 31
+};
+
+template <bool NARROW>
+__device__ __forceinline__ void fir_fast2(FirLane2& f, int err) {
+    const int nb = __builtin_amdgcn_ds_bpermute(f.bpaddr, f.bphi ? f.hist[1] : f.hist[0]);
+    const int d0 = wsub(f.hist[0], f.base), d1 = wsub(f.hist[1], f.base);
+    const int p = NARROW ? wadd(__mul24(d0, f.coef[0]), __mul24(d1, f.coef[1]))
+                         : wadd(wmul(d0, f.coef[0]), wmul(d1, f.coef[1]));
+    const int sum = row_allreduce_n<4>(p);
+    const int outg = __builtin_amdgcn_sbfe(wadd(wadd(wadd(f.rnd, sum) >> f.q, f.base), err), 0, f.rss);
+    const int outd = __builtin_amdgcn_sbfe(wadd(f.prev, err), 0, f.rss);
+    const int out = f.delta ? outd : outg;
+    const int s = err >> 31;
+    const int rq = s & f.qmask;
+    const int a0 = max(d0, -d0), a1 = max(d1, -d1);
+    const uint32_t q0 = (uint32_t)(a0 + rq) >> f.q, q1 = (uint32_t)(a1 + rq) >> f.q;
+    uint32_t c0 = NARROW ? __umul24(q0, f.w[0]) : q0 * f.w[0];
+    uint32_t c1 = NARROW ? __umul24(q1, f.w[1]) : q1 * f.w[1];
+    c0 = min(c0, 1u << 26);
+    c1 = min(c1, 1u << 26);
+    const uint32_t i1 = (uint32_t)row_suffix_scan_n<4>((int)c1);
+    const uint32_t t1 = (uint32_t)row_allreduce_n<4>((int)c1);
+    const uint32_t i0 = (uint32_t)row_suffix_scan_n<4>((int)c0) + t1;
+    const uint32_t E = (uint32_t)((err ^ s) - s);
+    int sd0, sd1;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(sd0) : "v"(d0), "v"(f.tlo[0]), "v"(f.thi[0]));
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(sd1) : "v"(d1), "v"(f.tlo[1]), "v"(f.thi[1]));
+    f.coef[1] += (E + c1 > i1) ? (sd1 ^ s) - s : 0;
+    f.coef[0] += (E + c0 > i0) ? (sd0 ^ s) - s : 0;
+    const int carry = __builtin_amdgcn_update_dpp(0, f.hist[0], DPP_ROW_ROR1, 0xF, 0xF, false);
+    f.hist[1] = __builtin_amdgcn_update_dpp(carry, f.hist[1], DPP_ROW_SHR1, 0xF, 0xF, false);
+    f.hist[0] = __builtin_amdgcn_update_dpp(out, f.hist[0], DPP_ROW_SHR1, 0xF, 0xF, false);
+    f.base = nb;
+    f.prev = out;
+}
+
 // ---- "P8" layout: 8 lanes per stream, the two channels of a packet interleaved in one row -----------------
 // For streams with 1 <= N <= 8.  Row r = packet r of the wave; lane l of the row: channel = l & 1, tap j = l >> 1.
 // Every DPP pattern below moves data between lanes of equal parity, i.e. inside one stream: the dot product is

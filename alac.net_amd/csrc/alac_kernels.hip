@@ -605,6 +605,24 @@ __device__ void recon_wave_impl(const alac_decode_params& p, const Meta& m, bool
     fl.bpaddr = (rowlane0 + (stream_on ? (m.N - 1) & 15 : 0)) * 4;
     const int* qzero = &sh.zeros[0][g];
 
+    // ---- two-register fast path (some stream of the wave has more than 16 taps, or is in delta mode) ----
+    const bool row_ok2 = !stream_on || m.N >= 1;
+    const bool can_fast2 = TPL == 2 && !__builtin_amdgcn_ballot_w64(!row_ok2) && nmax > 0;
+    const int Nw2 = __builtin_amdgcn_readfirstlane(wave_max((stream_on && m.N != 31) ? m.N : 0));
+    FirLane2 f2;
+    f2.q = fl.q; f2.rnd = fl.rnd; f2.rss = fl.rss; f2.qmask = fl.qmask;
+    f2.delta = stream_on && m.N == 31;
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int j = l + 16 * t;
+        const bool tp = stream_on && m.N != 31 && j < m.N;
+        f2.tlo[t] = tp ? -1 : 0;
+        f2.thi[t] = tp ? 1 : 0;
+        f2.w[t] = tp ? (uint32_t)(m.N - j) : 0u;
+    }
+    f2.bphi = stream_on && m.N != 31 && m.N > 16;
+    f2.bpaddr = (rowlane0 + ((stream_on && m.N != 31) ? (m.N - 1) & 15 : 0)) * 4;
+
     unsigned long long rwait = 0;
     for (int c = 0; c < nchunks; c++) {
         const int i0 = c * CHUNK;
@@ -636,6 +654,36 @@ __device__ void recon_wave_impl(const alac_decode_params& p, const Meta& m, bool
                 f.coef[0] = fl.coef;
                 f.base = fl.base;
                 f.prev = __shfl(fl.hist, rowlane0, 64);
+            } else if (TPL == 2 && can_fast2 && i0 > Nw2 && i0 + CHUNK <= nmin) {
+                f2.hist[0] = f.hist[0];
+                f2.hist[1] = f.hist[TPL - 1];
+                f2.coef[0] = f.coef[0];
+                f2.coef[1] = f.coef[TPL - 1];
+                f2.base = f.base;
+                f2.prev = f.prev;
+                const int* qf = stream_on ? q : qzero;
+                int err = qf[0];
+                if (narrow) {
+#pragma unroll
+                    for (int ii = 0; ii < CHUNK; ii++) {
+                        const int en = qf[(ii + 1 < CHUNK ? ii + 1 : ii) * S];
+                        fir_fast2<true>(f2, err);
+                        err = en;
+                    }
+                } else {
+#pragma unroll
+                    for (int ii = 0; ii < CHUNK; ii++) {
+                        const int en = qf[(ii + 1 < CHUNK ? ii + 1 : ii) * S];
+                        fir_fast2<false>(f2, err);
+                        err = en;
+                    }
+                }
+                f.hist[0] = f2.hist[0];
+                f.hist[TPL - 1] = f2.hist[1];
+                f.coef[0] = f2.coef[0];
+                f.coef[TPL - 1] = f2.coef[1];
+                f.base = f2.base;
+                f.prev = f2.prev;
             } else {
                 for (int ii = 0; ii < CHUNK; ii++) {
                     const int i = i0 + ii;
@@ -801,7 +849,7 @@ __device__ void recon_wave(const alac_decode_params& p, uint32_t pkt0, int w, in
     const bool valid = pkt < p.n_packets;
     alacgpu_cfg_dev cfg;
     const Meta m = parse_meta(p, pkt, chan, valid, cfg);
-    const bool wide = valid && m.status == 0 && !m.esc && m.N > 16 && m.N <= 30 && (chan == 0 || m.stereo);
+    const bool wide = valid && m.status == 0 && !m.esc && m.N > 16 && (chan == 0 || m.stereo);   // incl. N == 31 (delta mode)
     if (__builtin_amdgcn_ballot_w64(wide))
         recon_wave_impl<F, 2>(p, m, valid, g, chan, lane, sh, nchunks, pkt);
     else
