@@ -231,7 +231,20 @@ int alacgpu_decode_batch_device(alacgpu_ctx* ctx, const void* d_blob, uint64_t b
         unsigned long long* h = (unsigned long long*)std::malloc(sizeof(unsigned long long) * 8 * nwg);
         HIP_TRY(ctx, hipMemcpy(h, d, sizeof(unsigned long long) * 8 * nwg, hipMemcpyDeviceToHost));
         double acc[8] = {0}; uint32_t cnt = 0;
-        for (uint32_t w = 0; w < nwg; w++) { if (!h[8 * w]) continue; cnt++; for (int j = 1; j < 8; j++) acc[j] += (double)(h[8 * w + j] - h[8 * w]); }
+        double mx_end = 0, mn_end = 1e30, mx_pre = 0; unsigned long long t_first = ~0ull, t_last = 0;
+        for (uint32_t w = 0; w < nwg; w++) {
+            if (!h[8 * w]) continue;
+            cnt++;
+            for (int j = 1; j < 8; j++) acc[j] += (double)(h[8 * w + j] - h[8 * w]);
+            const double e = (double)(h[8 * w + 2] - h[8 * w]);
+            mx_end = e > mx_end ? e : mx_end; mn_end = e < mn_end ? e : mn_end;
+            const double pe = (double)(h[8 * w + 1] - h[8 * w]);
+            mx_pre = pe > mx_pre ? pe : mx_pre;
+            if (h[8 * w] < t_first) t_first = h[8 * w];
+            if (h[8 * w + 2] > t_last) t_last = h[8 * w + 2];
+        }
+        if (cnt) std::fprintf(stderr, "[alacgpu stamps] per-WG entropy_end min=%.0f max=%.0f  prescan_end max=%.0f  first WG start -> last WG end = %.0f\n",
+                              mn_end, mx_end, mx_pre, (double)(t_last - t_first));
         if (cnt) std::fprintf(stderr, "[alacgpu stamps] wgs=%u  prescan_end=%.0f  entropy_end=%.0f  recon_first_chunk=%.0f  recon_end=%.0f  entropy_barrier_wait=%.0f  recon_barrier_wait=%.0f (cycles from WG start)  main_units_redone=%.1f per WG\n",
                               cnt, acc[1] / cnt, acc[2] / cnt, acc[3] / cnt, acc[4] / cnt, acc[5] / cnt, acc[6] / cnt, acc[7] / cnt);
         std::free(h); (void)hipFree(d);
