@@ -358,7 +358,11 @@ __device__ void entropy_wave(const alac_decode_params& p, uint32_t pkt0, int lan
     rs.w0 = rs.w1 = rs.w2 = 0; rs.rem = 0; rs.next = 12; rs.hist = 0; rs.signmod = 0; rs.zrun = 0; rs.nforce = 0;
     rs.ra = rs.ra_sync = lds_addr(sh.rings[g]);
     uint32_t filled = 0;
-    if (p.dbg && lane == 0) p.dbg[8 * blockIdx.x + 0] = clock64();
+    if (p.dbg && lane == 0) {
+        p.dbg[8 * blockIdx.x + 0] = clock64();
+        const unsigned hw = __builtin_amdgcn_s_getreg(63492), xcc = __builtin_amdgcn_s_getreg(63508);
+        p.dbg[8 * blockIdx.x + 3] = ((unsigned long long)xcc << 32) | hw;   // placement (HW_ID, XCC_ID)
+    }
 
     // ---- pre-scan: Rice-only pass over the A stream of every stereo packet, to find where B starts ----
     // Lanes with nothing to scan shadow the first scanning group (same ring, same state), so the whole

@@ -64,29 +64,33 @@ int launch(alacgpu_ctx* ctx, const alac_decode_params& p, hipStream_t stream) {
     // (a quarter as many entropy waves).  Measured on MI355X: cfg2 (4096 packets) 1.27 / 1.33 / 1.42 ms for 4 / 8 / 16
     // packets per workgroup, cfg3 (8192 packets) 8.5 / 7.1 / 6.9 ms.
     if (variant == 0) variant = p.n_packets >= (ctx->all_mono ? 12288u : 6144u) ? (ctx->all_mono ? 4 : 5) : 3;
-    HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
+    // Pick the kernel and its geometry.
+    const void* fn = nullptr;
+    uint32_t ppw = 2, threads = 64;    // packets per workgroup, workgroup size
     switch (variant) {
-    case 1:
-        hipLaunchKernelGGL(alac_decode_packets_kernel, dim3((p.n_packets + 1) / 2), dim3(64), 0, stream, p);
-        break;
-    case 2:
-        hipLaunchKernelGGL(alac_decode_split1_kernel, dim3((p.n_packets + 1) / 2), dim3(128), 0, stream, p);
-        break;
-    case 5:
-        hipLaunchKernelGGL(alac_decode_split8_kernel, dim3((p.n_packets + 15) / 16), dim3(576), 0, stream, p);
-        break;
+    case 1: fn = (const void*)alac_decode_packets_kernel; ppw = 2; threads = 64; break;
+    case 2: fn = (const void*)alac_decode_split1_kernel; ppw = 2; threads = 128; break;
+    case 5: fn = (const void*)alac_decode_split8_kernel; ppw = 16; threads = 576; break;
     case 4:
-        if (ctx->all_mono)
-            hipLaunchKernelGGL(alac_decode_split4_mono_kernel, dim3((p.n_packets + 15) / 16), dim3(320), 0, stream, p);
-        else
-            hipLaunchKernelGGL(alac_decode_split4_kernel, dim3((p.n_packets + 7) / 8), dim3(320), 0, stream, p);
+        if (ctx->all_mono) { fn = (const void*)alac_decode_split4_mono_kernel; ppw = 16; }
+        else { fn = (const void*)alac_decode_split4_kernel; ppw = 8; }
+        threads = 320;
         break;
     default:
-        if (ctx->all_mono)
-            hipLaunchKernelGGL(alac_decode_split2_mono_kernel, dim3((p.n_packets + 7) / 8), dim3(192), 0, stream, p);
-        else
-            hipLaunchKernelGGL(alac_decode_split2_kernel, dim3((p.n_packets + 3) / 4), dim3(192), 0, stream, p);
+        if (ctx->all_mono) { fn = (const void*)alac_decode_split2_mono_kernel; ppw = 8; }
+        else { fn = (const void*)alac_decode_split2_kernel; ppw = 4; }
+        threads = 192;
         break;
+    }
+    const uint32_t grid = (p.n_packets + ppw - 1) / ppw;
+    // (Workgroup placement was checked with HW_ID stamps: a 1024-workgroup grid lands as exactly 4 per CU on all
+    // 256 CUs, so no occupancy padding is needed to balance it.)
+    const uint32_t dyn_lds = 0;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
+    {
+        alac_decode_params args = p;
+        void* kargs[] = {&args};
+        HIP_TRY(ctx, hipLaunchKernel(fn, dim3(grid), dim3(threads), kargs, dyn_lds, stream));
     }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
@@ -247,6 +251,9 @@ int alacgpu_decode_batch_device(alacgpu_ctx* ctx, const void* d_blob, uint64_t b
                               mn_end, mx_end, mx_pre, (double)(t_last - t_first));
         if (cnt) std::fprintf(stderr, "[alacgpu stamps] wgs=%u  prescan_end=%.0f  entropy_end=%.0f  recon_first_chunk=%.0f  recon_end=%.0f  entropy_barrier_wait=%.0f  recon_barrier_wait=%.0f (cycles from WG start)  main_units_redone=%.1f per WG\n",
                               cnt, acc[1] / cnt, acc[2] / cnt, acc[3] / cnt, acc[4] / cnt, acc[5] / cnt, acc[6] / cnt, acc[7] / cnt);
+        if (const char* dump = std::getenv("ALACGPU_DEBUG_STAMPS_FILE")) {   // raw per-WG stamps for offline analysis
+            if (FILE* f = std::fopen(dump, "wb")) { std::fwrite(h, sizeof(unsigned long long), (size_t)8 * nwg, f); std::fclose(f); }
+        }
         std::free(h); (void)hipFree(d);
         return rc;
     }
