@@ -272,7 +272,10 @@ __device__ __forceinline__ T wave_max(T v) {
 // symbol (history < 128 after a value) is beyond all tiers: the function then returns false with the state
 // restored, and the caller decodes the unit with rice_step.  After an escape was seen the wave stays on tier 3 for
 // FULL_HOLD clean units (escapes come in stretches, and a failed cheaper attempt costs a whole unit).
-constexpr int FULL_HOLD = 4;
+#ifndef ALAC_FULL_HOLD
+#define ALAC_FULL_HOLD 1
+#endif
+constexpr int FULL_HOLD = ALAC_FULL_HOLD;
 
 template <bool WANT_R, int QSTRIDE>
 __device__ __forceinline__ bool spec_unit(Rice& rs, int& full_left, const RiceCfg& c, uint32_t ring, int* q) {
