@@ -333,6 +333,46 @@ __device__ __forceinline__ void ring_fill(uint32_t* ring, uint32_t& filled, uint
     }
 }
 
+// Refill with the global-load latency hidden: the loads for the next top-up are issued at the START of a
+// 16-sample chunk (the space they go to is already free then) and written to the ring at its END.
+// A chunk consumes at most ~118 bytes, so topping up by up to K x (LPS*16) >= 128 bytes per chunk keeps the ring
+// as full as ring_fill does.
+template <int LPS>
+struct RingPrefetch {
+    static constexpr int K = (128 + LPS * 16 - 1) / (LPS * 16);
+    uint4 v[K];
+    uint32_t cnt;
+};
+template <int LPS>
+__device__ __forceinline__ void ring_prefetch_issue(RingPrefetch<LPS>& pf, uint32_t filled, uint32_t next,
+                                                    const uint8_t* base, int64_t limit, int l, bool enable) {
+    constexpr uint32_t C = LPS * 16;
+    pf.cnt = 0;
+#pragma unroll
+    for (int k = 0; k < RingPrefetch<LPS>::K; k++) {
+        const bool need = enable && (filled + (uint32_t)(k + 1) * C <= (next - 12u) + RING_BYTES);
+        pf.v[k] = make_uint4(0, 0, 0, 0);
+        if (need) {
+            const int64_t off = (int64_t)filled + (int64_t)k * C + l * 16;
+            if (off + 16 <= limit) pf.v[k] = *reinterpret_cast<const uint4*>(base + off);
+            pf.cnt = (uint32_t)(k + 1);
+        }
+    }
+}
+template <int LPS>
+__device__ __forceinline__ void ring_prefetch_commit(const RingPrefetch<LPS>& pf, uint32_t* ring, uint32_t& filled, int l) {
+    constexpr uint32_t C = LPS * 16;
+#pragma unroll
+    for (int k = 0; k < RingPrefetch<LPS>::K; k++) {
+        if ((uint32_t)k < pf.cnt) {
+            const uint32_t off = filled + (uint32_t)k * C + (uint32_t)l * 16u;
+            const uint4 o = make_uint4(__builtin_bswap32(pf.v[k].x), __builtin_bswap32(pf.v[k].y),
+                                       __builtin_bswap32(pf.v[k].z), __builtin_bswap32(pf.v[k].w));
+            *reinterpret_cast<uint4*>(&ring[(off & RING_MASK) >> 2]) = o;
+        }
+    }
+    filled += pf.cnt * C;
+}
 template <int LPS>
 __device__ __forceinline__ void rice_init(Rice& s, uint32_t& filled, uint32_t startbit, int init_hist, uint32_t* ring,
                                           const uint8_t* base, int64_t limit, int l, bool enable) {

@@ -400,6 +400,8 @@ __device__ void entropy_wave(const alac_decode_params& p, uint32_t pkt0, int lan
             int dummy = 0;
             int i = 0;
             for (; i + CHUNK <= nmin - 1; i += CHUNK) {   // every lane has a sample left after each of these
+                RingPrefetch<LPS> pf;
+                ring_prefetch_issue<LPS>(pf, filled, rs.next, m.base, m.limit, sub, pre_on);
                 for (int u = 0; u < CHUNK; u += SPEC_UNIT) {
                     const bool redo = !spec_unit<false, 0>(rs, full_left, pc, pring, nullptr);
                     if (redo) {
@@ -409,7 +411,7 @@ __device__ void entropy_wave(const alac_decode_params& p, uint32_t pkt0, int lan
                 }
                 wave_sync();
                 rice_sync(rs);
-                ring_fill<LPS>(sh.rings[g], filled, rs.next, m.base, m.limit, sub, pre_on);
+                ring_prefetch_commit<LPS>(pf, sh.rings[g], filled, sub);
                 wave_sync();
             }
             for (; i < nmax; i++) {                        // ragged tail, generic
@@ -462,7 +464,11 @@ __device__ void entropy_wave(const alac_decode_params& p, uint32_t pkt0, int lan
         // residual queue slot of this stream; lanes other than the group's first write to a dummy word
         int* q = (sub == 0) ? &sh.resq[c & 1][0][g] : &sh.dummy[lane];
         if (i0 < nmax) {
-            if (i0 + CHUNK <= nmin - 1) {                  // fast chunk: all lanes decode, a sample always remains
+            const bool fast_chunk = i0 + CHUNK <= nmin - 1;   // all lanes decode, a sample always remains
+            RingPrefetch<LPS> pf;
+            pf.cnt = 0;
+            if (fast_chunk) {
+                ring_prefetch_issue<LPS>(pf, filled, rs.next, m.base, m.limit, sub, stream_on && i0 + CHUNK < n_row);
                 for (int u = 0; u < CHUNK; u += SPEC_UNIT) {
                     const bool redo = !spec_unit<true, S>(rs, full_left, mc, mring, q + u * S);
                     if (redo) nredo++;
@@ -482,7 +488,8 @@ __device__ void entropy_wave(const alac_decode_params& p, uint32_t pkt0, int lan
             }
             wave_sync();
             rice_sync(rs);
-            ring_fill<LPS>(sh.rings[g], filled, rs.next, m.base, m.limit, sub, stream_on && i0 + CHUNK < n_row);
+            if (fast_chunk) ring_prefetch_commit<LPS>(pf, sh.rings[g], filled, sub);
+            else ring_fill<LPS>(sh.rings[g], filled, rs.next, m.base, m.limit, sub, stream_on && i0 + CHUNK < n_row);
         }
         const unsigned long long tb = p.dbg ? clock64() : 0;
         wg_sync();  // chunk c is ready for the reconstruction waves
