@@ -510,7 +510,7 @@ __device__ __forceinline__ void fir_fast(FirLane& f, int err) {
     const int a = max(d, -d);
     const uint32_t aq = (uint32_t)(a + (s & f.qmask)) >> f.q;
     uint32_t cc = NARROW ? __umul24(aq, f.w) : aq * f.w;
-    cc = min(cc, 1u << 26);
+    if (!NARROW) cc = min(cc, 1u << 26);   // NARROW: |d| <= 2^18, w <= 16 -> the sums stay below 2^27 by themselves
     const uint32_t incl = (uint32_t)row_suffix_scan_n<NRED>((int)cc);
     const uint32_t Ecc = (uint32_t)((err ^ s) - s) + cc;      // |err| + own decrement: visit iff |err| > incl - cc
     // sign(d) for tap lanes, 0 elsewhere (tlo/thi are -1/+1 on tap lanes and 0/0 on the others)
@@ -553,8 +553,10 @@ __device__ __forceinline__ void fir_fast2(FirLane2& f, int err) {
     const uint32_t q0 = (uint32_t)(a0 + rq) >> f.q, q1 = (uint32_t)(a1 + rq) >> f.q;
     uint32_t c0 = NARROW ? __umul24(q0, f.w[0]) : q0 * f.w[0];
     uint32_t c1 = NARROW ? __umul24(q1, f.w[1]) : q1 * f.w[1];
-    c0 = min(c0, 1u << 26);
-    c1 = min(c1, 1u << 26);
+    if (!NARROW) {   // NARROW: |d| <= 2^18, w <= 31 -> the sums stay below 2^28 by themselves
+        c0 = min(c0, 1u << 26);
+        c1 = min(c1, 1u << 26);
+    }
     const uint32_t i1 = (uint32_t)row_suffix_scan_n<4>((int)c1);
     const uint32_t t1 = (uint32_t)row_allreduce_n<4>((int)c1);
     const uint32_t i0 = (uint32_t)row_suffix_scan_n<4>((int)c0) + t1;
@@ -610,7 +612,7 @@ __device__ __forceinline__ void fir8_step(Fir8Lane& f, int err, int i, bool acti
     const int a = max(d, -d);
     const uint32_t aq = (uint32_t)(a + (s & f.qmask)) >> f.q;
     uint32_t cc = NARROW ? __umul24(aq, f.w) : aq * f.w;
-    cc = min(cc, 1u << 26);
+    if (!NARROW) cc = min(cc, 1u << 26);   // NARROW: |d| <= 2^18, w <= 16 -> the sums stay below 2^27 by themselves
     uint32_t incl = cc;
     incl += (uint32_t)dpp0<DPP_ROW_SHL_2>((int)incl);
     incl += (uint32_t)dpp0<DPP_ROW_SHL_4>((int)incl);
