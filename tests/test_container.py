@@ -98,3 +98,43 @@ def test_alaccontext_seek(synth):
             # SetPosition sets LastSampleNumber to the END of the frame (AlacContext.cs:283) and the following Read
             # adds the frame's duration once more (:199): the reference's double count, reproduced
             assert ctx.LastSampleNumber == (frame + 2) * 4096
+
+
+def _fnv(data):
+    h = 1469598103934665603
+    for x in data:
+        h = ((h ^ x) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sample_size", [16, 24])
+def test_cpp_alaccontext_mirror(synth, tmp_path, sample_size):
+    # alac.net_amd/host/AlacContext.hpp: C++ twin of the demuxer + AlacContext surface, driven like the reference's callers
+    import os
+    import subprocess
+    import alac.net_amd as pkg
+
+    exe = os.path.join(os.path.dirname(pkg.__file__), "host", "alaccontext_selftest")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    data, packets, pcm, d = make_file(synth, n_packets=13, sample_size=sample_size, last=999)
+    path = tmp_path / "t.m4a"
+    path.write_bytes(data)
+    out = subprocess.run([exe, str(path)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    bps = sample_size // 8
+    exp = b"".join(int(v).to_bytes(4, "little", signed=True)[:bps] for v in pcm)
+    total = int(d["n"].sum())
+    assert out.stdout.strip() == (f"rate=44100 channels=2 bits={sample_size} samples={total} bytes={len(exp)} "
+                                  f"fnv={_fnv(exp)} last={total}"), out.stdout
+    if sample_size == 16:
+        pos = 4096 * 5 + 321
+        out = subprocess.run([exe, str(path), str(pos)], capture_output=True, text=True, timeout=120)
+        exp = pcm[pos * 2: 6 * 4096 * 2].astype("<i2").tobytes()
+        assert out.stdout.strip() == f"seek bytes={len(exp)} fnv={_fnv(exp)} last={7 * 4096}", out.stdout
+    # the reference rejects mdat-before-moov files (QTMovieT.cs:746): same exception text as AlacContext.cs:50
+    bad, *_ = make_file(synth, n_packets=2, mdat_first=True)
+    p2 = tmp_path / "bad.m4a"
+    p2.write_bytes(bad)
+    out = subprocess.run([exe, str(p2)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 1 and "Error while loading the QuickTime movie headers." in out.stdout

@@ -310,3 +310,31 @@ def test_p8_layout_random(pkg, oracle, synth, variant, stereo, is24):
     g, o = run_both(pkg, oracle, b, variant=variant)
     assert (o[3] == 0).all()
     assert_same(g, o, b["stream_cfgs"], None)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_tiny_batches_and_degenerate_packets(pkg, oracle, synth, variant):
+    # partially filled workgroups (1, 2, 3, 5 packets) and packets of 0 / 1 / 2 / 5 bytes (everything past the end
+    # reads as zeros for both decoders: each packet is followed by zero padding)
+    src = synth.make_config_batch(2, n_packets=5, want_pcm=True)
+    for npk in (1, 2, 3, 5):
+        b = dict(src)
+        b["offsets"], b["sizes"] = src["offsets"][:npk], src["sizes"][:npk]
+        g, o = run_both(pkg, oracle, b, variant=variant)
+        assert (o[3] == 0).all()
+        assert_same(g, o, b["stream_cfgs"], None)
+        assert np.array_equal(g[0], src["pcm"][:npk])
+    blob = bytearray()
+    offs, sizes = [], []
+    first = bytes(src["blob"][: int(src["sizes"][0])])
+    for cut in (0, 1, 2, 5, 40, len(first)):
+        offs.append(len(blob))
+        sizes.append(cut)
+        blob += first[:cut] + bytes(96 * 1024)
+    b = dict(src)
+    b["blob"] = np.frombuffer(bytes(blob), dtype=np.uint8)
+    b["offsets"] = np.array(offs, dtype=np.uint64)
+    b["sizes"] = np.array(sizes, dtype=np.uint32)
+    g, o = run_both(pkg, oracle, b, variant=variant)
+    assert o[3].tolist()[-1] == 0 and all(s != 0 for s in o[3].tolist()[:-1])
+    assert_same(g, o, b["stream_cfgs"], None)
