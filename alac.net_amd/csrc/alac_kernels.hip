@@ -251,6 +251,7 @@ struct SplitShared {
     uint32_t rings[4 * F][RING_BYTES / 4];
     int resq[2][CHUNK][4 * F];
     int zeros[CHUNK][4 * F];   // residuals of a switched-off row
+    int outq[2][2][F >= 2 ? F / 2 : 1][64];   // P8 layout: FIR wave -> output wave, 8 outputs per stream per half chunk
     int dummy[CHUNK * 4 * F + 64];
 };
 
@@ -495,6 +496,7 @@ __device__ void entropy_wave(const alac_decode_params& p, uint32_t pkt0, int lan
         wg_sync();  // chunk c is ready for the reconstruction waves
         if (p.dbg) ewait += clock64() - tb;
     }
+    wg_sync();      // final barrier (every wave of the workgroup executes nchunks + 1): P8 FIR wave -> output wave
     if (p.dbg && lane == 0) {
         p.dbg[8 * blockIdx.x + 5] = p.dbg[8 * blockIdx.x + 0] + ewait;
         p.dbg[8 * blockIdx.x + 7] = p.dbg[8 * blockIdx.x + 0] + (unsigned long long)nredo;
@@ -710,14 +712,58 @@ __device__ void recon_wave_impl(const alac_decode_params& p, const Meta& m, bool
         }
         recon_output(p, m, f.hist[0], i0, n_out, lane, chan, pcm_slot);
     }
+    wg_sync();      // final barrier, see entropy_wave
     if (p.dbg && lane == 0 && g == 0) {
         p.dbg[8 * blockIdx.x + 4] = clock64();
         p.dbg[8 * blockIdx.x + 6] = p.dbg[8 * blockIdx.x + 0] + rwait;
     }
 }
 
-// Reconstruction wave in the P8 layout (see alac_device.h): 8 streams = 4 packets per wave.
-template <int F, bool MONO>
+// Output stage of the P8 layout for the 8 sample frames starting at ih: lane (2t + par) of a row holds
+// out[last - t] of its stream; the A/B partner of a sample is lane ^ 1.
+__device__ __forceinline__ void p8_output(const alac_decode_params& p, const Meta& m, int mine, int ih, int n_out, int j,
+                                          int chan, int32_t* pcm_slot) {
+    const int cnt = min(8, n_out - ih);
+    const bool live = j < cnt;
+    const int i = m.esc ? ih + j : ih + cnt - 1 - j;
+    if (live && m.esc && (chan == 0 || m.stereo)) {
+        const uint32_t bp = m.rawbit + (uint32_t)((i * (m.stereo ? 2 : 1) + chan) * m.ss);
+        mine = __builtin_amdgcn_sbfe((int)peek_bits(m.base, m.limit, bp, m.ss), 0, m.ss);
+    }
+    const int partner = __builtin_amdgcn_update_dpp(0, mine, DPP_QUAD_1032, 0xF, 0xF, false);
+    if (live) {
+        const int a = chan == 0 ? mine : partner, b = chan == 0 ? partner : mine;
+        int val;
+        if (m.stereo) {
+            int left, right;
+            if (m.mixweight != 0) {
+                right = wsub(a, wmul(b, m.mixweight) >> (m.mixshift & 31));
+                left = wadd(right, b);
+            } else {
+                left = a;
+                right = b;
+            }
+            val = chan == 0 ? left : right;
+        } else {
+            val = chan == 0 ? a : 0;
+        }
+        if (m.ss == 24) {
+            if (m.ub != 0 && !m.esc && (chan == 0 || m.stereo)) {
+                const uint32_t bp = m.ubit + (uint32_t)((i * (m.stereo ? 2 : 1) + chan) * 8 * m.ub);
+                const uint32_t sb = peek_bits(m.base, m.limit, bp, 8 * m.ub);
+                val = (int)(((uint32_t)val << (8 * m.ub)) | sb);
+            }
+            val = __builtin_amdgcn_sbfe(val, 0, 24);
+        }
+        if (chan < m.nc) store_sample(p, m, pcm_slot, (int64_t)i * m.nc + chan, val);
+    }
+}
+
+// Reconstruction in the P8 layout (see alac_device.h): 8 streams = 4 packets per wave.  Two waves share the job:
+// the COMPUTE wave runs the FIR and drops each batch of 8 outputs per stream into an LDS queue; the OUTPUT wave (one
+// of the reconstruction waves the P8 layout leaves idle) picks them up one chunk later and does the un-mixing, shift
+// bytes and stores -- about a tenth of the instructions, taken off the longest chain of the main pass.
+template <int F, bool MONO, bool OUTPUT_ROLE>
 __device__ void recon8_wave(const alac_decode_params& p, uint32_t pkt0, int w8, int lane, SplitShared<F>& sh, int nchunks,
                             bool narrow) {
     constexpr int S = 4 * F;
@@ -733,6 +779,17 @@ __device__ void recon8_wave(const alac_decode_params& p, uint32_t pkt0, int w8, 
     const int n_row = stream_on ? m.n : 0;
     const int n_out = (valid && m.status == 0) ? m.n : 0;
     int32_t* pcm_slot = p.pcm_out + (int64_t)pkt * p.slot_ints;
+
+    if (OUTPUT_ROLE) {
+        for (int c = 0; c <= nchunks; c++) {
+            wg_sync();  // barrier c (c == nchunks: the final one); chunk c-1's outputs are in the queue now
+            if (c == 0) continue;
+#pragma unroll
+            for (int half = 0; half < 2; half++)
+                p8_output(p, m, sh.outq[(c - 1) & 1][half][w8][lane], (c - 1) * CHUNK + 8 * half, n_out, j, chan, pcm_slot);
+        }
+        return;
+    }
 
     Fir8Lane f;
     f.hist = 0;
@@ -759,7 +816,7 @@ __device__ void recon8_wave(const alac_decode_params& p, uint32_t pkt0, int w8, 
         wg_sync();  // wait for chunk c
         const int* q = stream_on ? &sh.resq[c & 1][0][g] : qzero;
 #pragma unroll
-        for (int half = 0; half < 2; half++) {             // 8 lanes of history per stream: output every 8 steps
+        for (int half = 0; half < 2; half++) {             // 8 lanes of history per stream: hand over every 8 steps
             const int ih = i0 + 8 * half;
             if (ih < nmax) {
                 if (ih > 8 && ih + 8 <= nmin) {   // every switched-on stream is past its warm-up and has 8 samples left
@@ -788,44 +845,10 @@ __device__ void recon8_wave(const alac_decode_params& p, uint32_t pkt0, int w8, 
                     }
                 }
             }
-            // ---- output: lane (2t + chan) of the row holds out[last - t] ----
-            const int cnt = min(8, n_out - ih);
-            const bool live = j < cnt;
-            const int i = m.esc ? ih + j : ih + cnt - 1 - j;
-            int mine = f.hist;
-            if (live && m.esc && (chan == 0 || m.stereo)) {
-                const uint32_t bp = m.rawbit + (uint32_t)((i * (m.stereo ? 2 : 1) + chan) * m.ss);
-                mine = __builtin_amdgcn_sbfe((int)peek_bits(m.base, m.limit, bp, m.ss), 0, m.ss);
-            }
-            const int partner = __builtin_amdgcn_update_dpp(0, mine, DPP_QUAD_1032, 0xF, 0xF, false);
-            if (live) {
-                const int a = chan == 0 ? mine : partner, b = chan == 0 ? partner : mine;
-                int val;
-                if (m.stereo) {
-                    int left, right;
-                    if (m.mixweight != 0) {
-                        right = wsub(a, wmul(b, m.mixweight) >> (m.mixshift & 31));
-                        left = wadd(right, b);
-                    } else {
-                        left = a;
-                        right = b;
-                    }
-                    val = chan == 0 ? left : right;
-                } else {
-                    val = chan == 0 ? a : 0;
-                }
-                if (m.ss == 24) {
-                    if (m.ub != 0 && !m.esc && (chan == 0 || m.stereo)) {
-                        const uint32_t bp = m.ubit + (uint32_t)((i * (m.stereo ? 2 : 1) + chan) * 8 * m.ub);
-                        const uint32_t sb = peek_bits(m.base, m.limit, bp, 8 * m.ub);
-                        val = (int)(((uint32_t)val << (8 * m.ub)) | sb);
-                    }
-                    val = __builtin_amdgcn_sbfe(val, 0, 24);
-                }
-                if (chan < m.nc) store_sample(p, m, pcm_slot, (int64_t)i * m.nc + chan, val);
-            }
+            sh.outq[c & 1][half][w8][lane] = f.hist;   // lane (2t + par) holds out[last - t] of its stream
         }
     }
+    wg_sync();  // final barrier: the last chunk's outputs are in the queue
 }
 
 template <int F, bool MONO>
@@ -849,11 +872,8 @@ __device__ void recon_wave(const alac_decode_params& p, uint32_t pkt0, int w, in
         }
     }
     if (p8 && F >= 2) {
-        if (w < F / 2) {
-            recon8_wave<F, MONO>(p, pkt0, w, lane, sh, nchunks, narrow8);
-        } else {
-            for (int c = 0; c < nchunks; c++) wg_sync();   // nothing to do: keep the barrier count
-        }
+        if (w < F / 2) recon8_wave<F, MONO, false>(p, pkt0, w, lane, sh, nchunks, narrow8);          // FIR
+        else recon8_wave<F, MONO, true>(p, pkt0, w - F / 2, lane, sh, nchunks, narrow8);            // un-mix + store
         return;
     }
     const int row = lane >> 4;
