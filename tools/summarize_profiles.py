@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Turns gpurun_out/final/ (made by tools/collect_profiles.sh on the GPU box) into the committed evidence under
+profiles/ and prints the BASELINE.md results table.  usage: python tools/summarize_profiles.py <tag>"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r1_final"
+src = "gpurun_out/final"
+os.makedirs("profiles", exist_ok=True)
+
+
+def newest(pattern):
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
+shutil.copy(newest(f"{src}/stats/*/*_kernel_stats.csv"), f"profiles/{tag}_kernel_stats.csv")
+summary = {}
+kernel = None
+for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
+    rows = list(csv.DictReader(open(newest(f"{src}/{d}/*/*_counter_collection.csv"))))
+    agg, dur = collections.defaultdict(list), []
+    for r in rows:
+        if "alac" in r["Kernel_Name"]:
+            kernel = r["Kernel_Name"]
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            dur.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    summary[d] = {"kernel": kernel, "avg_kernel_ns": sum(dur) / len(dur),
+                  "counters_avg_per_launch": {k: sum(v) / len(v) for k, v in agg.items()}}
+bench = json.load(open(f"{src}/bench_default.json"))
+fetch_kb = summary["pmc_fetch"]["counters_avg_per_launch"]["FETCH_SIZE"]
+write_kb = summary["pmc_write"]["counters_avg_per_launch"]["WRITE_SIZE"]
+gui = summary["pmc_write"]["counters_avg_per_launch"]["GRBM_GUI_ACTIVE"]
+out = {
+    "command": "rocprofv3 --kernel-trace --pmc <counters> --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline"
+               "   (tools/collect_profiles.sh: one --pmc pass per counter group, no other tracing domain)",
+    "workload": bench["config"]["workload"],
+    "passes": summary,
+    "traffic": {
+        "FETCH_SIZE_KB_raw": fetch_kb, "WRITE_SIZE_KB": write_kb,
+        "gfx950_correction": "FETCH_SIZE reports 1/2 of the bytes of wide (16 B/lane) coalesced reads on gfx950 (MI355X_MICROARCH.md,"
+                             " HBM section): read bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE is exact",
+        "read_bytes_per_launch": 2 * fetch_kb * 1024, "write_bytes_per_launch": write_kb * 1024,
+        "hbm_bytes_per_launch": 2 * fetch_kb * 1024 + write_kb * 1024,
+        "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
+        "note": "reads are ~1.6x the packet bytes: the A stream of every stereo packet is read twice (pre-scan + main pass); the"
+                " 45 MB input blob stays cache resident across the repeated bench steps, so the read side is an upper bound on HBM"
+                " reads; writes equal the PCM bytes exactly",
+    },
+    "effective_clock_GHz": gui / 8 / summary["pmc_write"]["avg_kernel_ns"],
+}
+json.dump(out, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1)
+json.dump({"workload": "cfg2", "kernel": kernel, "hbm_bytes_per_launch": out["traffic"]["hbm_bytes_per_launch"],
+           "source": f"profiles/{tag}_pmc_summary.json"}, open("profiles/traffic_cfg2.json", "w"))
+shutil.copy(f"{src}/bench_default.json", f"profiles/{tag}_bench_cfg2.json")
+shutil.copy(f"{src}/cfg1_m4a.json", f"profiles/{tag}_cfg1_m4a.json")
+print(open(f"profiles/{tag}_kernel_stats.csv").read().splitlines()[1])
+print("traffic", out["traffic"]["hbm_bytes_per_launch"], "clock", out["effective_clock_GHz"])
+for d in summary:
+    print(d, round(summary[d]["avg_kernel_ns"]), {k: f"{v:.4g}" for k, v in summary[d]["counters_avg_per_launch"].items()})
+print()
+print("| config | packets / GPU | kernel | ms / batch | GPU Msamples/s | algorithmic GB/s | fraction of 8 TB/s | CPU 1 thread Msamples/s | GPU / CPU-1T | CPU all cores (256) Msamples/s |")
+print("|---|---|---|---|---|---|---|---|---|---|")
+for c in (2, 3, 4, 5):
+    j = json.load(open(f"{src}/cfg{c}.json"))
+    cb = j["cpu_baseline"]
+    print(f"| cfg{c} | {j['config']['packets_per_gpu']} | `{j['roofline']['kernel'].replace('alac_decode_', '').replace('_kernel', '')}` | "
+          f"{j['ms_per_step']:.3f} | {j['value']:.0f} | {j['roofline']['achieved']:.1f} | {j['roofline']['frac'] * 100:.2f} % | {cb['value']:.1f} | "
+          f"{j['value'] / cb['value']:.0f}x | {cb['all_cores_value']:.0f} | parity={j['parity_vs_oracle']}")
+print(open(f"{src}/cfg1_m4a.json").read())
