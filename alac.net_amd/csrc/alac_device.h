@@ -310,7 +310,7 @@ __device__ __forceinline__ int rice_spec_step_full(Rice& s, uint32_t& w3, const 
     s.zrun -= inrun ? 1 : 0;
     return r;
 }
-constexpr int SPEC_UNIT = 4;   // steps per speculative unit
+constexpr int SPEC_UNIT = 8;   // steps per speculative unit
 
 // ---- per-row LDS ring ------------------------------------------------------------------------------
 // Tops the ring up with 256-byte chunks while there is room in front of the oldest live dword.
