@@ -6,7 +6,12 @@
 // :256-336 = predictor_decompress_fir_adapt) and mid/side un-mixing + store (Deinterlace16/24
 // :338-421), integer only, bit-exact with the reference's C# int semantics.
 //
-// Mapping (v1, "fused row-per-stream"):
+// Two kernel families live here:
+//   v2 "split" (default; further down): per workgroup one entropy wave (pre-scan + Rice -> LDS residual queue)
+//       and reconstruction waves (FIR, un-mix, store), pipelined by one s_barrier per 16 samples;
+//   v1 "fused" (first, below): every lane group runs Rice and FIR itself.  Simplest correct form and A/B baseline.
+//
+// Mapping of v1, "fused row-per-stream":
 //   * one wave (64 lanes) = 4 rows of 16 lanes; a row owns one channel stream; a stereo packet is the
 //     row pair (A,B); a wave therefore decodes TWO packets (a workgroup is one wave).
 //   * the Rice state of a stream is replicated in its 16 lanes (row-uniform), so the residual is
