@@ -366,8 +366,12 @@ __device__ __forceinline__ void ring_prefetch_commit(const RingPrefetch<LPS>& pf
     for (int k = 0; k < RingPrefetch<LPS>::K; k++) {
         if ((uint32_t)k < pf.cnt) {
             const uint32_t off = filled + (uint32_t)k * C + (uint32_t)l * 16u;
-            const uint4 o = make_uint4(__builtin_bswap32(pf.v[k].x), __builtin_bswap32(pf.v[k].y),
-                                       __builtin_bswap32(pf.v[k].z), __builtin_bswap32(pf.v[k].w));
+            uint4 v = pf.v[k];
+            // pin the byte swap HERE: hoisted up to the load (the compiler does that when it can) it would wait for the
+            // global load at the start of the chunk and expose the latency this prefetch exists to hide
+            asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+            const uint4 o = make_uint4(__builtin_bswap32(v.x), __builtin_bswap32(v.y), __builtin_bswap32(v.z),
+                                       __builtin_bswap32(v.w));
             *reinterpret_cast<uint4*>(&ring[(off & RING_MASK) >> 2]) = o;
         }
     }
