@@ -1,6 +1,7 @@
 // alacgpu_api.hip -- C ABI of include/alacgpu.h on top of the gfx950 kernels.
 // No CPU fallback anywhere in this file: every decode goes through alac_decode_packets_kernel.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 
 #include <cstdio>
 #include <cstdlib>
@@ -296,7 +297,19 @@ int alacgpu_decode_batch(alacgpu_ctx* ctx, const uint8_t* blob, uint64_t blob_by
     rc = alacgpu_decode_batch_device(ctx, d_blob, blob_bytes, d_off, d_sz, cfg_idx ? d_ci : nullptr, n_packets, d_pcm,
                                      slot_ints, d_ob, d_os, d_st, s);
     if (rc) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(pcm_out, d_pcm, sizeof(int32_t) * (size_t)n_packets * slot_ints, hipMemcpyDeviceToHost, s));
+    if (ctx->out_format == ALACGPU_OUT_PACKED_LE) {
+        // a slot holds at most slot_ints samples of (ctor sample size / 8) bytes: copy that much of every slot
+        size_t bps = 2;
+        for (uint32_t i = 0; i < ctx->n_cfgs; i++) {
+            const int ss = ctx->h_cfgs[i].ctor_sample_size ? ctx->h_cfgs[i].ctor_sample_size : ctx->h_cfgs[i].sample_size;
+            bps = std::max(bps, (size_t)std::min(std::max(ss / 8, 2), 4));
+        }
+        const size_t pitch = sizeof(int32_t) * (size_t)slot_ints;
+        HIP_TRY(ctx, hipMemcpy2DAsync(pcm_out, pitch, d_pcm, pitch, std::min(pitch, bps * (size_t)slot_ints), n_packets,
+                                      hipMemcpyDeviceToHost, s));
+    } else {
+        HIP_TRY(ctx, hipMemcpyAsync(pcm_out, d_pcm, sizeof(int32_t) * (size_t)n_packets * slot_ints, hipMemcpyDeviceToHost, s));
+    }
     HIP_TRY(ctx, hipMemcpyAsync(status, d_st, sizeof(int32_t) * n_packets, hipMemcpyDeviceToHost, s));
     if (out_bytes) HIP_TRY(ctx, hipMemcpyAsync(out_bytes, d_ob, sizeof(int32_t) * n_packets, hipMemcpyDeviceToHost, s));
     if (out_samples) HIP_TRY(ctx, hipMemcpyAsync(out_samples, d_os, sizeof(int32_t) * n_packets, hipMemcpyDeviceToHost, s));

@@ -122,7 +122,9 @@ float alacgpu_last_kernel_ms(alacgpu_ctx* ctx);
 /* Output layout of the batch entry points.  ALACGPU_OUT_INT32 (default): one int32 per sample, as documented
  * above.  ALACGPU_OUT_PACKED_LE: the bytes AlacContext.Read hands out -- AlacContext.FormatSamples
  * (AlacContext.cs:214-256) fused into the kernel's store: packet p's little-endian PCM (2 or 3 bytes per sample,
- * interleaved) starts at (uint8_t*)(pcm_out + p*slot_ints) and is out_bytes[p] long.  The slot stride is unchanged. */
+ * interleaved) starts at (uint8_t*)(pcm_out + p*slot_ints) and is out_bytes[p] long.  The slot stride is unchanged;
+ * alacgpu_decode_batch then copies back only the part of each slot the widest stream cfg can fill (2 or 3 bytes per
+ * slot int), the rest of the caller's slot is left untouched. */
 enum { ALACGPU_OUT_INT32 = 0, ALACGPU_OUT_PACKED_LE = 1 };
 int alacgpu_set_output_format(alacgpu_ctx* ctx, int format);
 

@@ -292,6 +292,33 @@ def test_packed_output_equals_format_samples(pkg, oracle, synth, cfg, variant):
         assert np.array_equal(raw[p, : len(exp)], exp), f"packet {p}"
 
 
+@pytest.mark.parametrize("cfg", [2, 3])
+def test_host_path_reuses_the_callers_array_and_trims_the_packed_copy(pkg, oracle, synth, cfg):
+    # decode_batch(out=...) decodes into the caller's array (no fresh allocation); with packed output only the
+    # first 2 or 3 bytes per slot int come back over PCIe and the rest of the caller's slot is left alone
+    b = synth.make_config_batch(cfg, n_packets=40)
+    n, slot = len(b["sizes"]), int(b["slot_ints"])
+    bps = max(int(c[1]) // 8 for c in b["stream_cfgs"])
+    with pkg.AlacGpuContext(b["stream_cfgs"]) as ctx:
+        want = ctx.decode_batch(b["blob"], b["offsets"], b["sizes"], b["cfg_idx"], slot)
+        mine = np.full((n, slot), 0x5A5A5A5A, np.int32)
+        got = ctx.decode_batch(b["blob"], b["offsets"], b["sizes"], b["cfg_idx"], slot, out=mine)
+        assert got[0] is mine
+        for p in range(n):
+            cnt = int(want[2][p]) * int(b["stream_cfgs"][0 if b["cfg_idx"] is None else int(b["cfg_idx"][p])][5])
+            assert np.array_equal(mine[p, :cnt], want[0][p, :cnt])
+        with pytest.raises(ValueError):
+            ctx.decode_batch(b["blob"], b["offsets"], b["sizes"], b["cfg_idx"], slot, out=mine[:, :-1])
+        ctx.set_output_format(1)
+        packed = ctx.decode_batch(b["blob"], b["offsets"], b["sizes"], b["cfg_idx"], slot)
+        mine[:] = 0x5A5A5A5A
+        ctx.decode_batch(b["blob"], b["offsets"], b["sizes"], b["cfg_idx"], slot, out=mine)
+        raw, praw = mine.view(np.uint8), packed[0].view(np.uint8)
+        for p in range(n):
+            assert np.array_equal(raw[p, : packed[1][p]], praw[p, : packed[1][p]])
+        assert (raw[:, bps * slot:] == 0x5A).all()      # beyond what any packet of these cfgs can fill: untouched
+
+
 @pytest.mark.parametrize("variant", [3, 4])
 @pytest.mark.parametrize("stereo,is24", [(True, False), (True, True), (False, False)])
 def test_p8_layout_random(pkg, oracle, synth, variant, stereo, is24):
