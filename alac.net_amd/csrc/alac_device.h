@@ -83,8 +83,9 @@ __device__ __forceinline__ uint32_t lds_load(uint32_t a) { return *(const lds_u3
 // ---- Rice reader state (row-uniform) -------------------------------------------------------------
 struct Rice {
     uint32_t w0, w1, w2;  // three consecutive big-endian dwords; w2 is the prefetched one
-    int rem;              // unconsumed bits left in w0, 0..31
-    uint32_t ra;          // LDS byte address of w2's dword inside the (1 KiB aligned) ring
+    uint32_t cur;         // bit cursor, NOT normalised: cur & 31 = unconsumed bits left in w0 (what v_alignbit takes),
+                          // ~(cur >> 5) & 255 = ring dword of w2.  Consuming c bits is cur -= c (see rice_advance)
+    uint32_t ra;          // LDS byte address of w2's dword inside the (1 KiB aligned) ring == rice_w2_addr(cur)
     uint32_t ra_sync;     // value of ra when `next` was last brought up to date (rice_sync)
     uint32_t next;        // byte offset (from the aligned packet base) of the dword after w2; lazily updated
     int hist;             // history            (AlacFile.cs:216)
@@ -111,17 +112,28 @@ __device__ __forceinline__ uint32_t and_not(uint32_t b, uint32_t m) {  // b & ~m
     return r;
 }
 
-__device__ __forceinline__ uint32_t rice_window(const Rice& s) {
-    return __builtin_amdgcn_alignbit(s.w0, s.w1, s.rem);
+// The cursor that goes with `rem` unconsumed bits in w0 and w2 at LDS address ra.
+__device__ __forceinline__ uint32_t rice_cursor(int rem, uint32_t ra) {
+    return (uint32_t)rem - 32u - 8u * (ra & (uint32_t)RING_MASK);
 }
+// LDS address of w2 for a cursor (ring base is 1 KiB aligned): one v_lshrrev + one v_bitop3.
+__device__ __forceinline__ uint32_t rice_w2_addr(uint32_t cur, uint32_t ring) {
+    uint32_t a = (~(cur >> 3) & 0x3FCu) | ring;
+    asm("" : "+v"(a));   // keep it one three-input bit op; callers compare whole addresses
+    return a;
+}
+__device__ __forceinline__ uint32_t rice_window(const Rice& s) {
+    return __builtin_amdgcn_alignbit(s.w0, s.w1, s.cur);
+}
+// Consumes c <= 32 bits: the window slides by at most one dword, exactly when w2's address changes.
 __device__ __forceinline__ void rice_advance(Rice& s, int c, uint32_t ring) {
-    int rem = s.rem - c;
-    bool adv = rem < 0;
-    s.rem = rem & 31;
+    s.cur -= (uint32_t)c;
+    const uint32_t a2 = rice_w2_addr(s.cur, ring);
+    const bool adv = a2 != s.ra;
     s.w0 = adv ? s.w1 : s.w0;
     s.w1 = adv ? s.w2 : s.w1;
-    s.ra = ((s.ra + (adv ? 4u : 0u)) & RING_MASK) | ring;   // ring base is 1 KiB aligned: one v_and_or_b32
-    s.w2 = lds_load(s.ra);
+    s.ra = a2;
+    s.w2 = lds_load(a2);
 }
 // Brings s.next up to date.  Must be called at least once per RING_BYTES of consumption (callers do it
 // every 16 samples, <= 118 bytes) and before ring_fill / rice_bitpos.
@@ -129,7 +141,7 @@ __device__ __forceinline__ void rice_sync(Rice& s) {
     s.next += (s.ra - s.ra_sync) & RING_MASK;
     s.ra_sync = s.ra;
 }
-__device__ __forceinline__ uint32_t rice_bitpos(const Rice& s) { return (s.next - 12u) * 8u + 32u - (uint32_t)s.rem; }
+__device__ __forceinline__ uint32_t rice_bitpos(const Rice& s) { return (s.next - 12u) * 8u + 32u - (s.cur & 31u); }
 
 // One EntropyDecodeValue (AlacFile.cs:193-212).  m = ((1<<k)-1) & mask, escape_bits = rss or 16.
 __device__ __forceinline__ uint32_t rice_symbol(Rice& s, int k, uint32_t m, int escape_bits, uint32_t ring) {
@@ -214,7 +226,7 @@ __device__ __forceinline__ int rice_spec_step(Rice& s, const RiceCfg& c, uint32_
     const uint32_t e = __builtin_amdgcn_ubfe(win, (uint32_t)(31 - k) - x, (uint32_t)k);  // Readbits(k) (:205)
     const uint32_t m = __builtin_amdgcn_ubfe(0xFFFFFFFFu, 0u, (uint32_t)k);        // (1 << k) - 1
     const uint32_t v = __umul24(x, m) + (e > 1u ? e - 1u : 0u);                    // :206-208
-    const int rem2 = s.rem - (int)(x + (uint32_t)k) - (e > 1u ? 1 : 0);      // bits used: x+1+k, minus the un-read one (:210)
+    const uint32_t cur2 = s.cur - (x + (uint32_t)k) - (e > 1u ? 1u : 0u);    // bits used: x+1+k, minus the un-read one (:210)
     int r = 0;
     if (WANT_R) r = (int)(v >> 1) ^ -(int)(v & 1u);                          // :225-226
     const int h = s.hist;
@@ -222,12 +234,13 @@ __device__ __forceinline__ int rice_spec_step(Rice& s, const RiceCfg& c, uint32_
     asm volatile("" : "+v"(hx));   // keep this unconditional: a select, not an exec-masked branch
     const int hn = (int)v > 0xFFFF ? 0xFFFF : hx;                            // :229
     hmin = min(hmin, hn);
-    const bool adv = rem2 < 0;
-    s.rem = rem2 & 31;
+    const uint32_t a2 = rice_w2_addr(cur2, ring);
+    const bool adv = a2 != s.ra;
+    s.cur = cur2;
     s.w0 = adv ? s.w1 : s.w0;
     s.w1 = adv ? s.w2 : s.w1;
-    s.ra = ((s.ra + (adv ? 4u : 0u)) & RING_MASK) | ring;
-    s.w2 = lds_load(s.ra);
+    s.ra = a2;
+    s.w2 = lds_load(a2);
     s.hist = hn;
     return r;
 }
@@ -246,7 +259,7 @@ __device__ __forceinline__ int rice_spec_step_z(Rice& s, const RiceCfg& c, uint3
     const uint32_t e = __builtin_amdgcn_ubfe(win, (uint32_t)(31 - k) - x, (uint32_t)k);
     const uint32_t m = __builtin_amdgcn_ubfe(0xFFFFFFFFu, 0u, (uint32_t)k);
     const uint32_t v = __umul24(x, m) + (e > 1u ? e - 1u : 0u) + (uint32_t)s.signmod;   // :224
-    const int rem2 = inrun ? s.rem : s.rem - (int)(x + (uint32_t)k) - (e > 1u ? 1 : 0);
+    const uint32_t cur2 = inrun ? s.cur : s.cur - (x + (uint32_t)k) - (e > 1u ? 1u : 0u);
     int r = 0;
     if (WANT_R) r = inrun ? 0 : (int)(v >> 1) ^ -(int)(v & 1u);
     const int h = s.hist;
@@ -254,12 +267,13 @@ __device__ __forceinline__ int rice_spec_step_z(Rice& s, const RiceCfg& c, uint3
     asm volatile("" : "+v"(hx));
     const int hv = (int)v > 0xFFFF ? 0xFFFF : hx;
     hmin = min(hmin, inrun ? 0x7FFFFFFF : hv);
-    const bool adv = rem2 < 0;
-    s.rem = rem2 & 31;
+    const uint32_t a2 = rice_w2_addr(cur2, ring);
+    const bool adv = a2 != s.ra;
+    s.cur = cur2;
     s.w0 = adv ? s.w1 : s.w0;
     s.w1 = adv ? s.w2 : s.w1;
-    s.ra = ((s.ra + (adv ? 4u : 0u)) & RING_MASK) | ring;
-    s.w2 = lds_load(s.ra);
+    s.ra = a2;
+    s.w2 = lds_load(a2);
     s.hist = inrun ? h : hv;
     s.signmod = inrun ? s.signmod : 0;
     s.zrun -= inrun ? 1 : 0;
@@ -277,7 +291,7 @@ __device__ __forceinline__ int rice_spec_step_full(Rice& s, uint32_t& w3, const 
                                                    int& hmin) {
     const bool inrun = s.zrun > 0;
     const uint32_t win = rice_window(s);
-    const uint32_t win2 = __builtin_amdgcn_alignbit(s.w1, s.w2, s.rem);      // the 32 bits after `win`
+    const uint32_t win2 = __builtin_amdgcn_alignbit(s.w1, s.w2, s.cur);      // the 32 bits after `win`
     const uint32_t x = (uint32_t)__builtin_clz(~win | 0x00400000u);
     const bool esc = x > 8u;
     xmax = max(xmax, inrun ? 0u : x);
@@ -288,7 +302,7 @@ __device__ __forceinline__ int rice_spec_step_full(Rice& s, uint32_t& w3, const 
     const uint32_t raw = __builtin_amdgcn_alignbit(win, win2, 23) >> (32 - c.rss);   // bits 9 .. 9+rss of the stream
     const uint32_t v = (esc ? raw : vn) + (uint32_t)s.signmod;                        // :224
     const int used = esc ? 9 + c.rss : (int)(x + (uint32_t)k) + (e > 1u ? 1 : 0);
-    const int rem2 = inrun ? s.rem : s.rem - used;                            // >= -34
+    const uint32_t cur2 = inrun ? s.cur : s.cur - (uint32_t)used;             // up to 34 bits: w2 moves by 0, 1 or 2 dwords
     int r = 0;
     if (WANT_R) r = inrun ? 0 : (int)(v >> 1) ^ -(int)(v & 1u);
     const int h = s.hist;
@@ -296,15 +310,17 @@ __device__ __forceinline__ int rice_spec_step_full(Rice& s, uint32_t& w3, const 
     asm volatile("" : "+v"(hx));
     const int hv = (int)v > 0xFFFF ? 0xFFFF : hx;                             // :229 (hx is unused garbage when v is huge)
     hmin = min(hmin, inrun ? 0x7FFFFFFF : hv);
-    const bool a1 = rem2 < 0, a2 = rem2 < -32;
-    s.rem = rem2 & 31;
+    const uint32_t na = rice_w2_addr(cur2, ring);
+    const bool a1 = na != s.ra;                                               // slid by at least one dword
+    const bool a2 = na == (((s.ra + 8u) & RING_MASK) | ring);                 // slid by two
+    s.cur = cur2;
     const uint32_t n0 = a2 ? s.w2 : (a1 ? s.w1 : s.w0);
     const uint32_t n1 = a2 ? w3 : (a1 ? s.w2 : s.w1);
     s.w0 = n0;
     s.w1 = n1;
-    s.ra = ((s.ra + (a2 ? 8u : (a1 ? 4u : 0u))) & RING_MASK) | ring;
-    s.w2 = lds_load(s.ra);
-    w3 = lds_load(((s.ra + 4u) & RING_MASK) | ring);
+    s.ra = na;
+    s.w2 = lds_load(na);
+    w3 = lds_load(((na + 4u) & RING_MASK) | ring);
     s.hist = inrun ? h : hv;
     s.signmod = inrun ? s.signmod : 0;
     s.zrun -= inrun ? 1 : 0;
@@ -383,7 +399,6 @@ __device__ __forceinline__ void rice_init(Rice& s, uint32_t& filled, uint32_t st
     constexpr uint32_t FILL_CHUNK = LPS * 16;
     uint32_t p = startbit - 1u;   // startbit >= 23 always
     uint32_t d = (p >> 5) * 4u;   // byte offset of the dword holding bit startbit-1
-    s.rem = 31 - (int)(p & 31u);
     s.next = d + 12u;
     s.hist = init_hist;
     s.signmod = 0;
@@ -398,6 +413,7 @@ __device__ __forceinline__ void rice_init(Rice& s, uint32_t& filled, uint32_t st
     s.w2 = ring[((d + 8u) & RING_MASK) >> 2];
     s.ra = lds_addr(ring) | ((d + 8u) & RING_MASK);
     s.ra_sync = s.ra;
+    s.cur = rice_cursor(31 - (int)(p & 31u), s.ra);
 }
 
 // ---- FIR state: tap j = l + 16*t lives in lane l, register t ---------------------------------------

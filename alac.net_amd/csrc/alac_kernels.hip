@@ -68,9 +68,10 @@ __device__ void decode_wave(const alac_decode_params& p, const Meta& m, const al
     rc.rss = m.rss;
 
     Rice rs;
-    rs.w0 = rs.w1 = rs.w2 = 0; rs.rem = 0; rs.next = 12; rs.hist = 0; rs.signmod = 0; rs.zrun = 0; rs.nforce = 0;
+    rs.w0 = rs.w1 = rs.w2 = 0; rs.next = 12; rs.hist = 0; rs.signmod = 0; rs.zrun = 0; rs.nforce = 0;
     const uint32_t ringa = lds_addr(ring);
     rs.ra = rs.ra_sync = ringa;
+    rs.cur = rice_cursor(0, rs.ra);
     uint32_t filled = 0;
 
     // ---- pre-scan: Rice-only pass over channel A of stereo packets to find where B starts ----
@@ -364,8 +365,9 @@ __device__ void entropy_wave(const alac_decode_params& p, uint32_t pkt0, int lan
 
     int full_left = 0;   // > 0: stay on the escape-capable speculative tier (see spec_unit)
     Rice rs;
-    rs.w0 = rs.w1 = rs.w2 = 0; rs.rem = 0; rs.next = 12; rs.hist = 0; rs.signmod = 0; rs.zrun = 0; rs.nforce = 0;
+    rs.w0 = rs.w1 = rs.w2 = 0; rs.next = 12; rs.hist = 0; rs.signmod = 0; rs.zrun = 0; rs.nforce = 0;
     rs.ra = rs.ra_sync = lds_addr(sh.rings[g]);
+    rs.cur = rice_cursor(0, rs.ra);
     uint32_t filled = 0;
     if (p.dbg && lane == 0) {
         p.dbg[8 * blockIdx.x + 0] = clock64();
@@ -401,6 +403,7 @@ __device__ void entropy_wave(const alac_decode_params& p, uint32_t pkt0, int lan
                 rs.w0 = pringp[(d0 & RING_MASK) >> 2];
                 rs.w1 = pringp[((d0 + 4u) & RING_MASK) >> 2];
                 rs.w2 = pringp[((d0 + 8u) & RING_MASK) >> 2];
+                rs.cur = rice_cursor((int)(rs.cur & 31u), pring | ((d0 + 8u) & RING_MASK));
                 rs.ra = rs.ra_sync = pring | ((d0 + 8u) & RING_MASK);
             }
             int dummy = 0;
@@ -459,6 +462,7 @@ __device__ void entropy_wave(const alac_decode_params& p, uint32_t pkt0, int lan
             rs.w0 = mringp[(d0 & RING_MASK) >> 2];
             rs.w1 = mringp[((d0 + 4u) & RING_MASK) >> 2];
             rs.w2 = mringp[((d0 + 8u) & RING_MASK) >> 2];
+            rs.cur = rice_cursor((int)(rs.cur & 31u), mring | ((d0 + 8u) & RING_MASK));
             rs.ra = rs.ra_sync = mring | ((d0 + 8u) & RING_MASK);
         }
     }
