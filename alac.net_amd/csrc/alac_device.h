@@ -490,7 +490,8 @@ __device__ __forceinline__ int fir_step(Fir<TPL>& f, int err, int i, int N, int 
 
 // ---- FIR fast step --------------------------------------------------------------------------------
 // The steady state of fir_step for one tap register per lane (1 <= N <= 16, i > N), branch-free.
-// NARROW: every operand fits 24 bits (rss <= 17), so the full-rate 24-bit multipliers are exact.
+// Multiplies are the 32-bit v_mul_lo_u32: on gfx950 the 24-bit ones (v_mul_*24, v_mad_*24) issue at HALF its rate
+// (tools/ubench_issue.hip), so there is no narrow-operand variant; the clamp below covers every sample size.
 // NRED:   3 when every row of the wave has N <= 8 (taps live in lanes 0..7 only), else 4.
 // Lanes >= N keep coef == 0 and w == 0.  A row that is switched off is fed err = 0 / coef = 0 and just idles.
 struct FirLane {
@@ -518,19 +519,18 @@ __device__ __forceinline__ int row_suffix_scan_n(int v) {
     return v;
 }
 
-template <bool NARROW, int NRED>
+template <int NRED>
 __device__ __forceinline__ void fir_fast(FirLane& f, int err) {
     const int nb = __builtin_amdgcn_ds_bpermute(f.bpaddr, f.hist);   // tap N-1 = next step's base; needed last
     const int d = wsub(f.hist, f.base);                                       // :303
-    const int p = NARROW ? __mul24(d, f.coef) : wmul(d, f.coef);
+    const int p = wmul(d, f.coef);
     const int sum = row_allreduce_n<NRED>(p);
     const int out = __builtin_amdgcn_sbfe(wadd(wadd(wadd(f.rnd, sum) >> f.q, f.base), err), 0, f.rss);  // :306-310
     // sign-LMS (:312-332), parallel form -- see fir_step for the derivation
     const int s = err >> 31;
     const int a = max(d, -d);
     const uint32_t aq = (uint32_t)(a + (s & f.qmask)) >> f.q;
-    uint32_t cc = NARROW ? __umul24(aq, f.w) : aq * f.w;
-    if (!NARROW) cc = min(cc, 1u << 26);   // NARROW: |d| <= 2^18, w <= 16 -> the sums stay below 2^27 by themselves
+    uint32_t cc = min(aq * f.w, 1u << 26);   // clamp: keeps the scan from wrapping, decisions unchanged
     const uint32_t incl = (uint32_t)row_suffix_scan_n<NRED>((int)cc);
     const uint32_t Ecc = (uint32_t)((err ^ s) - s) + cc;      // |err| + own decrement: visit iff |err| > incl - cc
     // sign(d) for tap lanes, 0 elsewhere (tlo/thi are -1/+1 on tap lanes and 0/0 on the others)
@@ -557,12 +557,10 @@ struct FirLane2 {
     bool delta;    // N == 31
 };
 
-template <bool NARROW>
 __device__ __forceinline__ void fir_fast2(FirLane2& f, int err) {
     const int nb = __builtin_amdgcn_ds_bpermute(f.bpaddr, f.bphi ? f.hist[1] : f.hist[0]);
     const int d0 = wsub(f.hist[0], f.base), d1 = wsub(f.hist[1], f.base);
-    const int p = NARROW ? wadd(__mul24(d0, f.coef[0]), __mul24(d1, f.coef[1]))
-                         : wadd(wmul(d0, f.coef[0]), wmul(d1, f.coef[1]));
+    const int p = wadd(wmul(d0, f.coef[0]), wmul(d1, f.coef[1]));
     const int sum = row_allreduce_n<4>(p);
     const int outg = __builtin_amdgcn_sbfe(wadd(wadd(wadd(f.rnd, sum) >> f.q, f.base), err), 0, f.rss);
     const int outd = __builtin_amdgcn_sbfe(wadd(f.prev, err), 0, f.rss);
@@ -571,12 +569,7 @@ __device__ __forceinline__ void fir_fast2(FirLane2& f, int err) {
     const int rq = s & f.qmask;
     const int a0 = max(d0, -d0), a1 = max(d1, -d1);
     const uint32_t q0 = (uint32_t)(a0 + rq) >> f.q, q1 = (uint32_t)(a1 + rq) >> f.q;
-    uint32_t c0 = NARROW ? __umul24(q0, f.w[0]) : q0 * f.w[0];
-    uint32_t c1 = NARROW ? __umul24(q1, f.w[1]) : q1 * f.w[1];
-    if (!NARROW) {   // NARROW: |d| <= 2^18, w <= 31 -> the sums stay below 2^28 by themselves
-        c0 = min(c0, 1u << 26);
-        c1 = min(c1, 1u << 26);
-    }
+    const uint32_t c0 = min(q0 * f.w[0], 1u << 26), c1 = min(q1 * f.w[1], 1u << 26);   // clamp: see fir_step
     const uint32_t i1 = (uint32_t)row_suffix_scan_n<4>((int)c1);
     const uint32_t t1 = (uint32_t)row_allreduce_n<4>((int)c1);
     const uint32_t i0 = (uint32_t)row_suffix_scan_n<4>((int)c0) + t1;
@@ -613,11 +606,11 @@ struct Fir8Lane {
 
 // GENERIC = false: steady state (every stream of the wave switched on, i > N).  GENERIC = true: also the first
 // sample / warm-up samples (:284-293) and streams that are switched off or already finished (`active` false).
-template <bool NARROW, bool GENERIC>
+template <bool GENERIC>
 __device__ __forceinline__ void fir8_step(Fir8Lane& f, int err, int i, bool active) {
     const int nb = __builtin_amdgcn_ds_bpermute(f.bpaddr, f.hist);
     const int d = wsub(f.hist, f.base);                                       // :303
-    int p = NARROW ? __mul24(d, f.coef) : wmul(d, f.coef);
+    int p = wmul(d, f.coef);
     p = wadd(p, dpp0<DPP_QUAD_2301>(p));
     p = wadd(p, __builtin_amdgcn_update_dpp(0, p, DPP_ROW_ROR4, 0xF, 0xF, false));
     p = wadd(p, __builtin_amdgcn_update_dpp(0, p, DPP_ROW_ROR8, 0xF, 0xF, false));
@@ -631,8 +624,7 @@ __device__ __forceinline__ void fir8_step(Fir8Lane& f, int err, int i, bool acti
     const int s = err >> 31;
     const int a = max(d, -d);
     const uint32_t aq = (uint32_t)(a + (s & f.qmask)) >> f.q;
-    uint32_t cc = NARROW ? __umul24(aq, f.w) : aq * f.w;
-    if (!NARROW) cc = min(cc, 1u << 26);   // NARROW: |d| <= 2^18, w <= 16 -> the sums stay below 2^27 by themselves
+    uint32_t cc = min(aq * f.w, 1u << 26);   // clamp: keeps the scan from wrapping, decisions unchanged
     uint32_t incl = cc;
     incl += (uint32_t)dpp0<DPP_ROW_SHL_2>((int)incl);
     incl += (uint32_t)dpp0<DPP_ROW_SHL_4>((int)incl);

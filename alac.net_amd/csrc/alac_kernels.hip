@@ -616,7 +616,6 @@ __device__ void recon_wave_impl(const alac_decode_params& p, const Meta& m, bool
     const bool can_fast = TPL == 1 && !__builtin_amdgcn_ballot_w64(!row_ok) && nmax > 0;
     const int Nw = __builtin_amdgcn_readfirstlane(wave_max(stream_on ? m.N : 0));
     const int nmin = __builtin_amdgcn_readfirstlane(-wave_max(stream_on ? -m.n : -0x7FFFFFFF));
-    const bool narrow = !__builtin_amdgcn_ballot_w64(stream_on && m.rss > 17);
 
     FirLane fl;
     fl.q = stream_on ? m.q : 1;
@@ -663,17 +662,13 @@ __device__ void recon_wave_impl(const alac_decode_params& p, const Meta& m, bool
                 fl.base = f.base;
                 const int* qf = stream_on ? q : qzero;
                 int err = qf[0];
-#define ALAC_FAST_CHUNK(NARROW_, NRED_)                                   \
+#define ALAC_FAST_CHUNK(NRED_)                                            \
     _Pragma("unroll") for (int ii = 0; ii < CHUNK; ii++) {                \
         const int en = qf[(ii + 1 < CHUNK ? ii + 1 : ii) * S];            \
-        fir_fast<NARROW_, NRED_>(fl, err);                                \
+        fir_fast<NRED_>(fl, err);                                         \
         err = en;                                                         \
     }
-                if (narrow) {
-                    if (Nw <= 8) { ALAC_FAST_CHUNK(true, 3) } else { ALAC_FAST_CHUNK(true, 4) }
-                } else {
-                    if (Nw <= 8) { ALAC_FAST_CHUNK(false, 3) } else { ALAC_FAST_CHUNK(false, 4) }
-                }
+                if (Nw <= 8) { ALAC_FAST_CHUNK(3) } else { ALAC_FAST_CHUNK(4) }
 #undef ALAC_FAST_CHUNK
                 f.hist[0] = fl.hist;
                 f.coef[0] = fl.coef;
@@ -688,20 +683,11 @@ __device__ void recon_wave_impl(const alac_decode_params& p, const Meta& m, bool
                 f2.prev = f.prev;
                 const int* qf = stream_on ? q : qzero;
                 int err = qf[0];
-                if (narrow) {
 #pragma unroll
-                    for (int ii = 0; ii < CHUNK; ii++) {
-                        const int en = qf[(ii + 1 < CHUNK ? ii + 1 : ii) * S];
-                        fir_fast2<true>(f2, err);
-                        err = en;
-                    }
-                } else {
-#pragma unroll
-                    for (int ii = 0; ii < CHUNK; ii++) {
-                        const int en = qf[(ii + 1 < CHUNK ? ii + 1 : ii) * S];
-                        fir_fast2<false>(f2, err);
-                        err = en;
-                    }
+                for (int ii = 0; ii < CHUNK; ii++) {
+                    const int en = qf[(ii + 1 < CHUNK ? ii + 1 : ii) * S];
+                    fir_fast2(f2, err);
+                    err = en;
                 }
                 f.hist[0] = f2.hist[0];
                 f.hist[TPL - 1] = f2.hist[1];
@@ -773,8 +759,7 @@ __device__ __forceinline__ void p8_output(const alac_decode_params& p, const Met
 // of the reconstruction waves the P8 layout leaves idle) picks them up one chunk later and does the un-mixing, shift
 // bytes and stores -- about a tenth of the instructions, taken off the longest chain of the main pass.
 template <int F, bool MONO, bool OUTPUT_ROLE>
-__device__ void recon8_wave(const alac_decode_params& p, uint32_t pkt0, int w8, int lane, SplitShared<F>& sh, int nchunks,
-                            bool narrow) {
+__device__ void recon8_wave(const alac_decode_params& p, uint32_t pkt0, int w8, int lane, SplitShared<F>& sh, int nchunks) {
     constexpr int S = 4 * F;
     const int row = lane >> 4, l = lane & 15, par = l & 1, j = l >> 1;
     const int g = 8 * w8 + 2 * row + par;                  // stream index inside the workgroup
@@ -830,27 +815,17 @@ __device__ void recon8_wave(const alac_decode_params& p, uint32_t pkt0, int w8, 
             if (ih < nmax) {
                 if (ih > 8 && ih + 8 <= nmin) {   // every switched-on stream is past its warm-up and has 8 samples left
                     int err = q[(8 * half) * S];
-                    if (narrow) {
 #pragma unroll
-                        for (int ii = 0; ii < 8; ii++) {
-                            const int en = q[(8 * half + (ii < 7 ? ii + 1 : ii)) * S];
-                            fir8_step<true, false>(f, err, ih + ii, true);
-                            err = en;
-                        }
-                    } else {
-#pragma unroll
-                        for (int ii = 0; ii < 8; ii++) {
-                            const int en = q[(8 * half + (ii < 7 ? ii + 1 : ii)) * S];
-                            fir8_step<false, false>(f, err, ih + ii, true);
-                            err = en;
-                        }
+                    for (int ii = 0; ii < 8; ii++) {
+                        const int en = q[(8 * half + (ii < 7 ? ii + 1 : ii)) * S];
+                        fir8_step<false>(f, err, ih + ii, true);
+                        err = en;
                     }
                 } else {
                     for (int ii = 0; ii < 8; ii++) {
                         const int i = ih + ii;
                         const int err = q[(8 * half + ii) * S];
-                        if (narrow) fir8_step<true, true>(f, err, i, i < n_row);
-                        else fir8_step<false, true>(f, err, i, i < n_row);
+                        fir8_step<true>(f, err, i, i < n_row);
                     }
                 }
             }
@@ -863,7 +838,7 @@ __device__ void recon8_wave(const alac_decode_params& p, uint32_t pkt0, int w8, 
 template <int F, bool MONO>
 __device__ void recon_wave(const alac_decode_params& p, uint32_t pkt0, int w, int lane, SplitShared<F>& sh, int nchunks) {
     // ---- can the whole workgroup use the P8 layout?  Every wave evaluates all 4F streams the same way. ----
-    bool p8 = true, narrow8 = true;
+    bool p8 = true;
     {
         constexpr int S = 4 * F;
 #pragma unroll
@@ -877,12 +852,11 @@ __device__ void recon_wave(const alac_decode_params& p, uint32_t pkt0, int w, in
             const bool on = v && mm.status == 0 && !mm.esc && (gc == 0 || mm.stereo);
             const bool bad = on && (mm.N < 1 || mm.N > 8);
             if (__builtin_amdgcn_ballot_w64(bad)) p8 = false;
-            if (__builtin_amdgcn_ballot_w64(on && mm.rss > 17)) narrow8 = false;
         }
     }
     if (p8 && F >= 2) {
-        if (w < F / 2) recon8_wave<F, MONO, false>(p, pkt0, w, lane, sh, nchunks, narrow8);          // FIR
-        else recon8_wave<F, MONO, true>(p, pkt0, w - F / 2, lane, sh, nchunks, narrow8);            // un-mix + store
+        if (w < F / 2) recon8_wave<F, MONO, false>(p, pkt0, w, lane, sh, nchunks);          // FIR
+        else recon8_wave<F, MONO, true>(p, pkt0, w - F / 2, lane, sh, nchunks);            // un-mix + store
         return;
     }
     const int row = lane >> 4;

@@ -12,7 +12,6 @@ using namespace alacdev;
 
 #define STEPS 4096
 
-template <bool NARROW>
 __global__ __launch_bounds__(64) void kern(unsigned long long* out, int* sink, uint32_t seed) {
     __shared__ int resq[2][16][8];
     const int lane = threadIdx.x, l = lane & 15, par = l & 1, j = l >> 1, row = lane >> 4;
@@ -33,7 +32,7 @@ __global__ __launch_bounds__(64) void kern(unsigned long long* out, int* sink, u
 #pragma unroll
             for (int ii = 0; ii < 8; ii++) {
                 const int en = q[(8 * half + (ii < 7 ? ii + 1 : ii)) * 8];
-                fir8_step<NARROW, false>(f, err, 16 + ii, true);
+                fir8_step<false>(f, err, 16 + ii, true);
                 err = en;
             }
         }
@@ -43,14 +42,13 @@ __global__ __launch_bounds__(64) void kern(unsigned long long* out, int* sink, u
     if (f.hist + f.coef == 0x12345678) sink[0] = f.base;
 }
 
-template <bool NARROW>
 void run(const char* name, unsigned long long* d_out, int* d_sink) {
     printf("%-34s", name);
     for (int wps : {0, 1, 2, 3}) {
         const int grid = wps == 0 ? 1 : 1024 * wps;
-        kern<NARROW><<<grid, 64>>>(d_out, d_sink, 1);
+        kern<<<grid, 64>>>(d_out, d_sink, 1);
         hipDeviceSynchronize();
-        kern<NARROW><<<grid, 64>>>(d_out, d_sink, 2);
+        kern<<<grid, 64>>>(d_out, d_sink, 2);
         hipDeviceSynchronize();
         std::vector<unsigned long long> h(grid);
         hipMemcpy(h.data(), d_out, grid * 8, hipMemcpyDeviceToHost);
@@ -64,7 +62,6 @@ int main() {
     unsigned long long* d_out; int* d_sink;
     hipMalloc(&d_out, 8192 * 8); hipMalloc(&d_sink, 64);
     printf("clock64 ticks per sample of fir8_step, one wave per block; w/simd=0: a single wave on the chip\n");
-    run<true>("fir8_step narrow (rss <= 17)", d_out, d_sink);
-    run<false>("fir8_step wide", d_out, d_sink);
+    run("fir8_step", d_out, d_sink);
     return 0;
 }

@@ -35,6 +35,26 @@ __global__ __launch_bounds__(64) void kern(unsigned long long* out, int* sink, i
         if (K == 11) { REP16(asm volatile("v_cmp_lt_i32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a) : "v"(b) : "vcc");) }
         if (K == 12) { REP16(asm volatile("v_readlane_b32 %1, %0, 3\n v_add_u32 %0, %0, %1" : "+v"(a), "+s"(s0));) }
         if (K == 13) { REP16(asm volatile("v_alignbit_b32 %0, %0, %1, %2" : "+v"(a) : "v"(b), "v"(c));) }
+        if (K == 20) { REP16(asm volatile("v_add_u32 %0, %0, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(seed));) }
+        if (K == 21) { REP16(asm volatile("v_mul_lo_u32 %0, %0, %4\n v_mul_lo_u32 %1, %1, %4\n v_mul_lo_u32 %2, %2, %4\n v_mul_lo_u32 %3, %3, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(seed));) }
+        if (K == 22) { REP16(asm volatile("v_mad_u32_u24 %0, %0, %4, %4\n v_mad_u32_u24 %1, %1, %4, %4\n v_mad_u32_u24 %2, %2, %4, %4\n v_mad_u32_u24 %3, %3, %4, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(seed));) }
+        if (K == 23) { REP16(asm volatile("v_bfe_u32 %0, %0, %4, 5\n v_bfe_u32 %1, %1, %4, 5\n v_bfe_u32 %2, %2, %4, 5\n v_bfe_u32 %3, %3, %4, 5" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(seed));) }
+        if (K == 24) { REP16(asm volatile("v_alignbit_b32 %0, %0, %4, %4\n v_alignbit_b32 %1, %1, %4, %4\n v_alignbit_b32 %2, %2, %4, %4\n v_alignbit_b32 %3, %3, %4, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(seed));) }
+        if (K == 25) { REP16(asm volatile("v_sad_u32 %0, %0, %4, %4\n v_sad_u32 %1, %1, %4, %4\n v_sad_u32 %2, %2, %4, %4\n v_sad_u32 %3, %3, %4, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(seed));) }
+        if (K == 26) { REP16(asm volatile("v_cndmask_b32 %0, %0, %4, vcc\n v_cndmask_b32 %1, %1, %4, vcc\n v_cndmask_b32 %2, %2, %4, vcc\n v_cndmask_b32 %3, %3, %4, vcc" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(seed) : "vcc");) }
+        if (K == 27) { REP16(asm volatile("v_bitop3_b32 %0, %0, %4, %4 bitop3:0x26\n v_bitop3_b32 %1, %1, %4, %4 bitop3:0x26\n v_bitop3_b32 %2, %2, %4, %4 bitop3:0x26\n v_bitop3_b32 %3, %3, %4, %4 bitop3:0x26" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(seed));) }
+        if (K == 28) { REP16(asm volatile("v_med3_i32 %0, %0, %4, %4\n v_med3_i32 %1, %1, %4, %4\n v_med3_i32 %2, %2, %4, %4\n v_med3_i32 %3, %3, %4, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(seed));) }
+        if (K == 29) { REP16(asm volatile("v_max3_u32 %0, %0, %4, %4\n v_max3_u32 %1, %1, %4, %4\n v_max3_u32 %2, %2, %4, %4\n v_max3_u32 %3, %3, %4, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(seed));) }
+        if (K == 30) { REP16(asm volatile("v_lshl_add_u32 %0, %0, 3, %4\n v_lshl_add_u32 %1, %1, 3, %4\n v_lshl_add_u32 %2, %2, 3, %4\n v_lshl_add_u32 %3, %3, 3, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(seed));) }
+        if (K == 31) { REP16(asm volatile("v_add3_u32 %0, %0, %4, %4\n v_add3_u32 %1, %1, %4, %4\n v_add3_u32 %2, %2, %4, %4\n v_add3_u32 %3, %3, %4, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(seed));) }
+        if (K == 32) { REP16(asm volatile("v_ffbh_u32 %0, %0\n v_ffbh_u32 %1, %1\n v_ffbh_u32 %2, %2\n v_ffbh_u32 %3, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(seed));) }
+        if (K == 33) { REP16(asm volatile("v_mul_u32_u24 %0, %0, %4\n v_mul_u32_u24 %1, %1, %4\n v_mul_u32_u24 %2, %2, %4\n v_mul_u32_u24 %3, %3, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(seed));) }
+        if (K == 34) { REP16(asm volatile("v_sub_u32 %0, %0, 1 clamp\n v_sub_u32 %1, %1, 1 clamp\n v_sub_u32 %2, %2, 1 clamp\n v_sub_u32 %3, %3, 1 clamp" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(seed));) }
+        if (K == 35) { REP16(asm volatile("v_and_or_b32 %0, %0, %4, %4\n v_and_or_b32 %1, %1, %4, %4\n v_and_or_b32 %2, %2, %4, %4\n v_and_or_b32 %3, %3, %4, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(seed));) }
+        if (K == 36) { REP16(asm volatile("v_bfe_i32 %0, %0, 0, 7\n v_bfe_i32 %1, %1, 0, 7\n v_bfe_i32 %2, %2, 0, 7\n v_bfe_i32 %3, %3, 0, 7" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(seed));) }
+        if (K == 37) { REP16(asm volatile("v_subb_co_u32 %0, vcc, %0, %4, vcc\n v_subb_co_u32 %1, vcc, %1, %4, vcc\n v_subb_co_u32 %2, vcc, %2, %4, vcc\n v_subb_co_u32 %3, vcc, %3, %4, vcc" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(seed) : "vcc");) }
+        if (K == 38) { REP16(asm volatile("v_max_i32 %0, %0, %4\n v_max_i32 %1, %1, %4\n v_max_i32 %2, %2, %4\n v_max_i32 %3, %3, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(seed));) }
+        if (K == 39) { REP16(asm volatile("v_add_u32_dpp %0, %0, %0 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_u32_dpp %1, %1, %1 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_u32_dpp %2, %2, %2 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_u32_dpp %3, %3, %3 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(seed));) }
         if (K == 14) { REP16(asm volatile("v_lshlrev_b64 %0, %1, %0" : "+v"(*(long long*)&lds[0]) : "v"(b));) }
     }
 done:
@@ -84,5 +104,26 @@ int main() {
     run<6>("ds_read_b32 dep (+wait)", 1, d_out, d_sink);
     run<7>("ds_bpermute dep (+wait)", 1, d_out, d_sink);
     run<8>("v_add dep, exec low half", 1, d_out, d_sink);
+    printf("throughput, 4 independent chains of one instruction:\n");
+    run<20>("4x v_add_u32", 4, d_out, d_sink);
+    run<21>("4x v_mul_lo_u32", 4, d_out, d_sink);
+    run<22>("4x v_mad_u32_u24", 4, d_out, d_sink);
+    run<23>("4x v_bfe_u32", 4, d_out, d_sink);
+    run<24>("4x v_alignbit_b32", 4, d_out, d_sink);
+    run<25>("4x v_sad_u32", 4, d_out, d_sink);
+    run<26>("4x v_cndmask_b32 (vcc)", 4, d_out, d_sink);
+    run<27>("4x v_bitop3_b32", 4, d_out, d_sink);
+    run<28>("4x v_med3_i32", 4, d_out, d_sink);
+    run<29>("4x v_max3_u32", 4, d_out, d_sink);
+    run<30>("4x v_lshl_add_u32", 4, d_out, d_sink);
+    run<31>("4x v_add3_u32", 4, d_out, d_sink);
+    run<32>("4x v_ffbh_u32", 4, d_out, d_sink);
+    run<33>("4x v_mul_u32_u24", 4, d_out, d_sink);
+    run<34>("4x v_sub_u32 clamp (VOP3)", 4, d_out, d_sink);
+    run<35>("4x v_and_or_b32", 4, d_out, d_sink);
+    run<36>("4x v_bfe_i32", 4, d_out, d_sink);
+    run<37>("4x v_subb_co_u32", 4, d_out, d_sink);
+    run<38>("4x v_max_i32", 4, d_out, d_sink);
+    run<39>("4x v_add_u32_dpp (own chain; hazard nops NOT added)", 4, d_out, d_sink);
     return 0;
 }
