@@ -46,7 +46,6 @@ extern "C" __global__ void alac_decode_packets_kernel(alac_decode_params p);   /
 extern "C" __global__ void alac_decode_split1_kernel(alac_decode_params p);    // v2: 1 entropy + 1 recon wave, 2 packets
 extern "C" __global__ void alac_decode_split2_kernel(alac_decode_params p);    // v2: 1 entropy + 2 recon waves, 4 packets
 extern "C" __global__ void alac_decode_split4_kernel(alac_decode_params p);    // v2: 1 entropy + 4 recon waves, 8 packets
-extern "C" __global__ void alac_decode_split8_kernel(alac_decode_params p);    // v2: 1 entropy + 8 recon waves, 16 packets
 extern "C" __global__ void alac_decode_split2_mono_kernel(alac_decode_params p);  // one-channel streams: 8 packets / WG
 extern "C" __global__ void alac_decode_split4_mono_kernel(alac_decode_params p);  // one-channel streams: 16 packets / WG
 #endif

@@ -910,7 +910,6 @@ __device__ __forceinline__ void split_kernel_body(const alac_decode_params& p) {
 extern "C" __global__ __launch_bounds__(128) void alac_decode_split1_kernel(alac_decode_params p) { split_kernel_body<1, false>(p); }
 extern "C" __global__ __launch_bounds__(192) void alac_decode_split2_kernel(alac_decode_params p) { split_kernel_body<2, false>(p); }
 extern "C" __global__ __launch_bounds__(320, 6) void alac_decode_split4_kernel(alac_decode_params p) { split_kernel_body<4, false>(p); }
-extern "C" __global__ __launch_bounds__(576, 6) void alac_decode_split8_kernel(alac_decode_params p) { split_kernel_body<8, false>(p); }
 // one-channel streams: 8 / 16 packets per workgroup, no pre-scan
 extern "C" __global__ __launch_bounds__(192) void alac_decode_split2_mono_kernel(alac_decode_params p) { split_kernel_body<2, true>(p); }
 extern "C" __global__ __launch_bounds__(320, 6) void alac_decode_split4_mono_kernel(alac_decode_params p) { split_kernel_body<4, true>(p); }

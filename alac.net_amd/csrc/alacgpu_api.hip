@@ -60,18 +60,19 @@ int ensure_ws(alacgpu_ctx* ctx, size_t bytes) {
 int launch(alacgpu_ctx* ctx, const alac_decode_params& p, hipStream_t stream) {
     if (p.n_packets == 0) return ALACGPU_OK;
     int variant = ctx->variant;
-    // auto: up to ~4 workgroups per CU the 4-packet workgroup (1 entropy + 2 reconstruction waves) has the
-    // shortest critical path; bigger batches are throughput bound and do better with 8 packets per workgroup
-    // (a quarter as many entropy waves).  Measured on MI355X: cfg2 (4096 packets) 1.27 / 1.33 / 1.42 ms for 4 / 8 / 16
-    // packets per workgroup, cfg3 (8192 packets) 8.5 / 7.1 / 6.9 ms.
-    if (variant == 0) variant = p.n_packets >= (ctx->all_mono ? 12288u : 6144u) ? (ctx->all_mono ? 4 : 5) : 3;
+    // auto: while every workgroup is resident at once (up to ~5 per CU) the small workgroup (1 entropy + 2
+    // reconstruction waves: 4 stereo / 8 mono packets) has the shortest critical path; bigger batches are throughput
+    // bound and do better with twice the packets per workgroup (half as many entropy waves per packet).  Measured on
+    // MI355X, cfg2, small / big workgroup: 4096 packets 0.99 / 1.08 ms, 8192 packets 2.14 / 1.37 ms (49 Gsamples/s:
+    // 1024 big workgroups are exactly one resident round), 32768 packets 7.1 / 6.2 ms; mono cfg4: 8192 packets
+    // 0.67 / 0.69 ms, 16384 packets 1.60 / 0.99 ms.  (A 16-packet workgroup was never better and is gone.)
+    if (variant == 0) variant = p.n_packets > (ctx->all_mono ? 10240u : 5120u) ? 4 : 3;
     // Pick the kernel and its geometry.
     const void* fn = nullptr;
     uint32_t ppw = 2, threads = 64;    // packets per workgroup, workgroup size
     switch (variant) {
     case 1: fn = (const void*)alac_decode_packets_kernel; ppw = 2; threads = 64; break;
     case 2: fn = (const void*)alac_decode_split1_kernel; ppw = 2; threads = 128; break;
-    case 5: fn = (const void*)alac_decode_split8_kernel; ppw = 16; threads = 576; break;
     case 4:
         if (ctx->all_mono) { fn = (const void*)alac_decode_split4_mono_kernel; ppw = 16; }
         else { fn = (const void*)alac_decode_split4_kernel; ppw = 8; }
@@ -166,7 +167,7 @@ int alacgpu_create(const alacgpu_cfg* cfgs, uint32_t n_cfgs, int device, alacgpu
     ctx->n_cfgs = n_cfgs;
     ctx->all_mono = true;
     for (uint32_t i = 0; i < n_cfgs; i++) ctx->all_mono = ctx->all_mono && cfgs[i].num_channels == 1;
-    if (const char* v = std::getenv("ALACGPU_KERNEL_VARIANT")) ctx->variant = std::atoi(v) >= 0 && std::atoi(v) <= 5 ? std::atoi(v) : 0;
+    if (const char* v = std::getenv("ALACGPU_KERNEL_VARIANT")) ctx->variant = std::atoi(v) >= 0 && std::atoi(v) <= 4 ? std::atoi(v) : 0;
     int rc = ALACGPU_OK;
     do {
         if (hipSetDevice(device) != hipSuccess) { rc = ALACGPU_ERR_NO_DEVICE; break; }
@@ -389,7 +390,7 @@ int alacgpu_set_output_format(alacgpu_ctx* ctx, int format) {
 }
 
 int alacgpu_set_kernel_variant(alacgpu_ctx* ctx, int variant) {
-    if (!ctx || variant < 0 || variant > 5) return ALACGPU_ERR_BAD_ARG;
+    if (!ctx || variant < 0 || variant > 4) return ALACGPU_ERR_BAD_ARG;
     ctx->variant = variant;
     return ALACGPU_OK;
 }

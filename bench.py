@@ -185,12 +185,10 @@ def main():
         }
 
     if rank == 0:
-        auto = 5 if n_packets >= 6144 else 3   # mirrors the library's auto choice (alacgpu_api.hip: launch)
         all_mono = all(c[5] == 1 for c in b["stream_cfgs"])
-        if all_mono:
-            auto = 4 if n_packets >= 12288 else 3
+        auto = 4 if n_packets > (10240 if all_mono else 5120) else 3   # mirrors the library's choice (alacgpu_api.hip: launch)
         kernel_name = {1: "alac_decode_packets_kernel", 2: "alac_decode_split1_kernel", 3: "alac_decode_split2_kernel",
-                       4: "alac_decode_split4_kernel", 5: "alac_decode_split8_kernel"}[args.variant or auto]
+                       4: "alac_decode_split4_kernel"}[args.variant or auto]
         if all_mono and (args.variant or auto) in (3, 4):
             kernel_name = kernel_name.replace("_kernel", "_mono_kernel")
         # HBM traffic comes from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read in-process):

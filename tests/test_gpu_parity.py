@@ -19,7 +19,7 @@ def pkg():
     return p
 
 
-VARIANTS = [1, 2, 3, 4, 5]
+VARIANTS = [1, 2, 3, 4]
 
 
 def run_both(pkg, oracle, b, n_threads=8, variant=0):
