@@ -36,6 +36,10 @@ namespace ALACdotNET.Decoder
             [Out] int[] pcmOut, uint slotInts, [Out] int[] outBytes, [Out] int[] outSamples, [Out] int[] status);
         [DllImport(Lib)] public static extern int alacgpu_decode_frame(IntPtr ctx, uint cfgIndex, [In] byte[] inbuffer, uint inBytes,
             [Out] int[] outbuffer, uint outCapacityInts, out int outBytes, out int status);
+        /// <summary>0: one int per sample (default); 1: packed little-endian PCM, the bytes AlacContext.Read returns
+        /// (AlacContext.FormatSamples fused into the store) at the start of every slot; out_bytes[p] of them.</summary>
+        [DllImport(Lib)] public static extern int alacgpu_set_output_format(IntPtr ctx, int format);
+        [DllImport(Lib)] public static extern IntPtr alacgpu_status_string(int status);
         [DllImport(Lib)] public static extern IntPtr alacgpu_strerror(int rc);
         [DllImport(Lib)] public static extern IntPtr alacgpu_last_error(IntPtr ctx);
 
