@@ -220,6 +220,24 @@ def test_full_size_cfg2_roundtrip_property(pkg, synth):
     assert np.array_equal(pcm, b["pcm"])
 
 
+@pytest.mark.parametrize("stereo", [True, False])
+def test_auto_kernel_choice_above_the_big_batch_threshold(pkg, oracle, synth, stereo):
+    # the library switches to the 8-packet (16 for mono) workgroups above 5120 (10240) packets: short packets keep the
+    # oracle fast; ragged sample counts and a last, partly filled workgroup included
+    count = 5203 if stereo else 10243
+    d = synth.packet_descs(count, n=96, max_samples_per_frame=4096, stereo=int(stereo))
+    rng = np.random.default_rng(count)
+    d["n"] = rng.integers(1, 129, count)
+    d["pred_order"] = rng.integers(1, 9, (count, 2))
+    b = synth.make_batch(d, synth.default_signal(11), want_pcm=True)
+    cfgs = [(4096, 16, 40, 10, 14, 2 if stereo else 1)]
+    o = oracle.decode_batch(oracle.make_cfgs(cfgs), b["blob"], b["offsets"], b["sizes"], None, b["slot_ints"], n_threads=8)
+    with pkg.AlacGpuContext(cfgs) as ctx:      # variant 0 = auto
+        g = ctx.decode_batch(b["blob"], b["offsets"], b["sizes"], None, b["slot_ints"])
+    assert (o[3] == 0).all()
+    assert_same(g, o, cfgs, None)
+
+
 def test_alacfile_mirror_decode_frame(pkg, oracle, synth):
     # the reference's own call sequence: new AlacFile(samplesize, numchannels); SetInfo(codecData); DecodeFrame(in, out)
     cd = [0] * 24 + [0, 0, 0x10, 0x00, 0, 24, 40, 10, 14, 2, 0, 255, 0, 0, 0x20, 0xE7, 0, 6, 0x9F, 0xE4, 0, 0, 0xAC, 0x44]
