@@ -238,6 +238,26 @@ def test_auto_kernel_choice_above_the_big_batch_threshold(pkg, oracle, synth, st
     assert_same(g, o, cfgs, None)
 
 
+@pytest.mark.parametrize("variant", [1, 3, 4])
+def test_maximum_frame_length(pkg, oracle, synth, variant):
+    # 16384 samples per channel is the reference's scratch size (AlacFile.cs:28): the longest frame it can decode.
+    # 24-bit, shift bytes, order 16 and a hassize header: the ring and the bit cursor wrap many times
+    d = synth.packet_descs(6, n=16384, max_samples_per_frame=16384, sample_size=24, stereo=1)
+    d["n"][:] = [16384, 16384, 16383, 8193, 16384, 1]
+    d["ub"][:] = [0, 1, 2, 1, 0, 1]
+    d["pred_order"][:, 0] = [16, 8, 31, 4, 30, 8]
+    d["pred_order"][:, 1] = [16, 8, 2, 4, 17, 8]
+    sig = synth.default_signal(2024)
+    sig["silence_prob"] = 0.5
+    b = synth.make_batch(d, sig, want_pcm=True)
+    b.update(stream_cfgs=[(16384, 24, 40, 10, 14, 2)], cfg_idx=None)
+    g, o = run_both(pkg, oracle, b, variant=variant)
+    assert (o[3] == 0).all()
+    assert_same(g, o, b["stream_cfgs"], None)
+    for p in range(6):
+        assert np.array_equal(g[0][p, : 2 * int(d["n"][p])], b["pcm"][p, : 2 * int(d["n"][p])])
+
+
 def test_alacfile_mirror_decode_frame(pkg, oracle, synth):
     # the reference's own call sequence: new AlacFile(samplesize, numchannels); SetInfo(codecData); DecodeFrame(in, out)
     cd = [0] * 24 + [0, 0, 0x10, 0x00, 0, 24, 40, 10, 14, 2, 0, 255, 0, 0, 0x20, 0xE7, 0, 6, 0x9F, 0xE4, 0, 0, 0xAC, 0x44]
