@@ -182,7 +182,7 @@ class AlacGpuContext:
         _check(lib().alacgpu_set_output_format(self._ctx, fmt), self._ctx)
 
     def set_kernel_variant(self, variant):
-        """0 auto, 1 fused kernel, 2/3/4 split kernel with 1/2/4 reconstruction waves (results identical)."""
+        """0 auto, 1 fused kernel, 2/3/4 split kernel with 1/2/4 reconstruction waves, 5 two-pass kernel (results identical)."""
         _check(lib().alacgpu_set_kernel_variant(self._ctx, variant), self._ctx)
 
     def last_kernel_ms(self):

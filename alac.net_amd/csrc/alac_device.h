@@ -215,7 +215,9 @@ __device__ __forceinline__ int rice_step(Rice& s, const RiceCfg& c, int remainin
 // steps afterwards and, if any lane left the common case, restore its snapshot and redo the unit with
 // rice_step.  A lane that has left the common case keeps running on garbage; that is harmless (LDS ring
 // reads are address-masked, nothing else is touched).
-template <bool WANT_R>
+// WANT_R: return the residual (else 0).  RAW: return the unsigned code value dv instead of the signed residual
+// (dv >> 1) ^ -(dv & 1) (:225-226) -- a consumer with cycles to spare does that conversion itself (fir8_step<.., true>).
+template <bool WANT_R, bool RAW = false>
 __device__ __forceinline__ int rice_spec_step(Rice& s, const RiceCfg& c, uint32_t ring, uint32_t& xmax,
                                               int& hmin) {
     const uint32_t win = rice_window(s);
@@ -228,7 +230,7 @@ __device__ __forceinline__ int rice_spec_step(Rice& s, const RiceCfg& c, uint32_
     const uint32_t v = __umul24(x, m) + (e > 1u ? e - 1u : 0u);                    // :206-208
     const uint32_t cur2 = s.cur - (x + (uint32_t)k) - (e > 1u ? 1u : 0u);    // bits used: x+1+k, minus the un-read one (:210)
     int r = 0;
-    if (WANT_R) r = (int)(v >> 1) ^ -(int)(v & 1u);                          // :225-226
+    if (WANT_R) r = RAW ? (int)v : (int)(v >> 1) ^ -(int)(v & 1u);           // :225-226
     const int h = s.hist;
     int hx = (int)(__umul24(v, (uint32_t)c.hist_mult) + (uint32_t)h) - (wmul(h, c.hist_mult) >> 9);
     asm volatile("" : "+v"(hx));   // keep this unconditional: a select, not an exec-masked branch
@@ -248,7 +250,7 @@ __device__ __forceinline__ int rice_spec_step(Rice& s, const RiceCfg& c, uint32_
 // silence): such a lane emits 0 without touching the bitstream while zrun > 0, and adds signModifier to
 // its next value.  Still straight-line; only a NEW run symbol (history < 128 after a value) or an escape
 // code sends the unit to rice_step.
-template <bool WANT_R>
+template <bool WANT_R, bool RAW = false>
 __device__ __forceinline__ int rice_spec_step_z(Rice& s, const RiceCfg& c, uint32_t ring, uint32_t& xmax,
                                                 int& hmin) {
     const bool inrun = s.zrun > 0;
@@ -261,7 +263,7 @@ __device__ __forceinline__ int rice_spec_step_z(Rice& s, const RiceCfg& c, uint3
     const uint32_t v = __umul24(x, m) + (e > 1u ? e - 1u : 0u) + (uint32_t)s.signmod;   // :224
     const uint32_t cur2 = inrun ? s.cur : s.cur - (x + (uint32_t)k) - (e > 1u ? 1u : 0u);
     int r = 0;
-    if (WANT_R) r = inrun ? 0 : (int)(v >> 1) ^ -(int)(v & 1u);
+    if (WANT_R) r = inrun ? 0 : (RAW ? (int)v : (int)(v >> 1) ^ -(int)(v & 1u));
     const int h = s.hist;
     int hx = (int)(__umul24(v, (uint32_t)c.hist_mult) + (uint32_t)h) - (wmul(h, c.hist_mult) >> 9);
     asm volatile("" : "+v"(hx));
@@ -286,7 +288,7 @@ __device__ __forceinline__ int rice_spec_step_z(Rice& s, const RiceCfg& c, uint3
 //     clamp (:229) keeps k small and escapes are frequent.  An escape consumes up to 9 + 25 bits, so the
 //     window slides by 0, 1 or 2 dwords per step and a fourth dword (w3) is kept prefetched.
 // Only a NEW run symbol (history < 128 after a value) sends the unit to rice_step.
-template <bool WANT_R>
+template <bool WANT_R, bool RAW = false>
 __device__ __forceinline__ int rice_spec_step_full(Rice& s, uint32_t& w3, const RiceCfg& c, uint32_t ring, uint32_t& xmax,
                                                    int& hmin) {
     const bool inrun = s.zrun > 0;
@@ -304,7 +306,7 @@ __device__ __forceinline__ int rice_spec_step_full(Rice& s, uint32_t& w3, const 
     const int used = esc ? 9 + c.rss : (int)(x + (uint32_t)k) + (e > 1u ? 1 : 0);
     const uint32_t cur2 = inrun ? s.cur : s.cur - (uint32_t)used;             // up to 34 bits: w2 moves by 0, 1 or 2 dwords
     int r = 0;
-    if (WANT_R) r = inrun ? 0 : (int)(v >> 1) ^ -(int)(v & 1u);
+    if (WANT_R) r = inrun ? 0 : (RAW ? (int)v : (int)(v >> 1) ^ -(int)(v & 1u));
     const int h = s.hist;
     int hx = (int)(__umul24(v, (uint32_t)c.hist_mult) + (uint32_t)h) - (wmul(h, c.hist_mult) >> 9);
     asm volatile("" : "+v"(hx));
@@ -606,8 +608,17 @@ struct Fir8Lane {
 
 // GENERIC = false: steady state (every stream of the wave switched on, i > N).  GENERIC = true: also the first
 // sample / warm-up samples (:284-293) and streams that are switched off or already finished (`active` false).
-template <bool GENERIC>
+// RAWQ: `err` arrives as the unsigned Rice code value dv (rice_spec_step<.., RAW>); the residual, its sign mask and its
+// magnitude come out of dv in four instructions, one more than from the residual itself.
+template <bool GENERIC, bool RAWQ = false>
 __device__ __forceinline__ void fir8_step(Fir8Lane& f, int err, int i, bool active) {
+    int s_raw = 0, mag_raw = 0;
+    if (RAWQ) {
+        s_raw = __builtin_amdgcn_sbfe(err, 0, 1);          // -(dv & 1)
+        const int hq = (int)((uint32_t)err >> 1);
+        mag_raw = hq - s_raw;                              // (dv + 1) >> 1
+        err = hq ^ s_raw;                                  // :225-226
+    }
     const int nb = __builtin_amdgcn_ds_bpermute(f.bpaddr, f.hist);
     const int d = wsub(f.hist, f.base);                                       // :303
     int p = wmul(d, f.coef);
@@ -621,7 +632,7 @@ __device__ __forceinline__ void fir8_step(Fir8Lane& f, int err, int i, bool acti
         if (i == 0) out = err;                                                // first sample copies
         else if (!general) out = __builtin_amdgcn_sbfe(wadd(f.prev, err), 0, f.rss);  // warm-up :284-293
     }
-    const int s = err >> 31;
+    const int s = RAWQ ? s_raw : err >> 31;
     const int a = max(d, -d);
     const uint32_t aq = (uint32_t)(a + (s & f.qmask)) >> f.q;
     uint32_t cc = min(aq * f.w, 1u << 26);   // clamp: keeps the scan from wrapping, decisions unchanged
@@ -629,7 +640,7 @@ __device__ __forceinline__ void fir8_step(Fir8Lane& f, int err, int i, bool acti
     incl += (uint32_t)dpp0<DPP_ROW_SHL_2>((int)incl);
     incl += (uint32_t)dpp0<DPP_ROW_SHL_4>((int)incl);
     incl += (uint32_t)dpp0<DPP_ROW_SHL_8>((int)incl);
-    const uint32_t Ecc = (uint32_t)((err ^ s) - s) + cc;
+    const uint32_t Ecc = (uint32_t)(RAWQ ? mag_raw : (err ^ s) - s) + cc;
     int sd;
     asm("v_med3_i32 %0, %1, %2, %3" : "=v"(sd) : "v"(d), "v"(f.tlo), "v"(f.thi));
     const bool visit = (Ecc > incl) && (!GENERIC || (general && active));

@@ -284,7 +284,7 @@ __device__ __forceinline__ T wave_max(T v) {
 #endif
 constexpr int FULL_HOLD = ALAC_FULL_HOLD;
 
-template <bool WANT_R, int QSTRIDE>
+template <bool WANT_R, int QSTRIDE, bool RAW = false>
 __device__ __forceinline__ bool spec_unit(Rice& rs, int& full_left, const RiceCfg& c, uint32_t ring, int* q) {
     const Rice snap = rs;
     const bool special = __builtin_amdgcn_ballot_w64(rs.nforce == 0u) != 0;
@@ -294,13 +294,13 @@ __device__ __forceinline__ bool spec_unit(Rice& rs, int& full_left, const RiceCf
         if (!special) {
 #pragma unroll
             for (int ii = 0; ii < SPEC_UNIT; ii++) {
-                const int r = rice_spec_step<WANT_R>(rs, c, ring, xmax, hmin);
+                const int r = rice_spec_step<WANT_R, RAW>(rs, c, ring, xmax, hmin);
                 if (WANT_R) q[ii * QSTRIDE] = r;
             }
         } else {
 #pragma unroll
             for (int ii = 0; ii < SPEC_UNIT; ii++) {
-                const int r = rice_spec_step_z<WANT_R>(rs, c, ring, xmax, hmin);
+                const int r = rice_spec_step_z<WANT_R, RAW>(rs, c, ring, xmax, hmin);
                 if (WANT_R) q[ii * QSTRIDE] = r;
             }
             rs.nforce = (rs.zrun > 0 || rs.signmod != 0) ? 0u : 0xFFFFFFFFu;
@@ -317,7 +317,7 @@ __device__ __forceinline__ bool spec_unit(Rice& rs, int& full_left, const RiceCf
     uint32_t w3 = lds_load(((rs.ra + 4u) & RING_MASK) | ring);
 #pragma unroll
     for (int ii = 0; ii < SPEC_UNIT; ii++) {
-        const int r = rice_spec_step_full<WANT_R>(rs, w3, c, ring, xmax, hmin);
+        const int r = rice_spec_step_full<WANT_R, RAW>(rs, w3, c, ring, xmax, hmin);
         if (WANT_R) q[ii * QSTRIDE] = r;
     }
     rs.nforce = (rs.zrun > 0 || rs.signmod != 0) ? 0u : 0xFFFFFFFFu;
@@ -879,6 +879,7 @@ __device__ __forceinline__ void split_kernel_body(const alac_decode_params& p) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     constexpr int PPW = MONO ? 4 * F : 2 * F;              // packets per workgroup
     const uint32_t pkt0 = blockIdx.x * (uint32_t)PPW;
+    if (p.ab_flags && p.ab_flags[pkt0 >> 3] == 0) return;   // the two-pass kernel decoded this group of 8 already
     // chunk count must be uniform over the workgroup: every wave derives it from all 2F headers
     int n_any = 0;
     {
@@ -902,11 +903,352 @@ __device__ __forceinline__ void split_kernel_body(const alac_decode_params& p) {
     }
 }
 
+
+// ===================================================================================================================
+// v3 "two-pass" kernel: 8 stereo packets per workgroup, three waves (entropy, output, FIR -- in that order, so that
+// consecutive workgroups placed round-robin on a CU's SIMDs never put two heavy waves on one SIMD).
+// Pass 0 decodes channel A of all 8 packets for real (entropy wave -> residual queue -> P8 FIR wave) and the output
+// wave parks the reconstructed samples in the upper half of the packet's own output slot; where pass 0 ends IS where
+// channel B starts, so there is no Rice-only pre-scan any more.  Pass 1 decodes channel B the same way and the output
+// wave un-mixes it with the parked A samples (read back one chunk ahead) and stores the PCM.  Both passes keep every
+// lane of the FIR wave busy (8 streams x 8 taps), which the one-pass layout only manages with both channels at once.
+// One-channel and uncompressed packets finish in pass 0.  Only for workgroups whose streams all fit the P8 layout
+// (1 <= N <= 8); others are flagged for the fallback launch of a split kernel (alac_decode_params::ab_flags).
+// Parking place: ints [n, 2n) of the slot (slot_ints >= 2n for two channels).  The final stores of sample i touch
+// at most int 2i+1 (int32 output) or byte 6i+5 (packed), always below the parked samples not yet consumed.
+// ===================================================================================================================
+constexpr int AB_PPW = 8;
+
+// One entropy pass over stream `g` of every lane group (S = 8 streams, 8 lanes each): the main pass of entropy_wave.
+// Returns the bit position after the last symbol; *flags collects rice_step's flags.
+// The queue of this kernel carries the unsigned code value dv, not the residual (the FIR wave has the cycles to spare
+// and converts it, fir8_step<.., true>): the inverse of r = (dv >> 1) ^ -(dv & 1) for what rice_step hands back.
+__device__ __forceinline__ int ab_zigzag(int r) { return (int)(((uint32_t)r << 1) ^ (uint32_t)(r >> 31)); }
+
+__device__ uint32_t ab_entropy_pass(const alac_decode_params& p, SplitShared<2>& sh, const Meta& m, const RiceCfg& rc, int init_hist,
+                                    uint32_t startbit, bool stream_on, int g, int sub, int lane, int nchunks, int* flags_out) {
+    constexpr int S = 8, LPS = 8;
+    const int n_row = stream_on ? m.n : 0;
+    int flags = 0;
+    int full_left = 0;
+    Rice rs;
+    rs.w0 = rs.w1 = rs.w2 = 0; rs.next = 12; rs.hist = 0; rs.signmod = 0; rs.zrun = 0; rs.nforce = 0;
+    rs.ra = rs.ra_sync = lds_addr(sh.rings[g]);
+    rs.cur = rice_cursor(0, rs.ra);
+    uint32_t filled = 0;
+    // lanes with nothing to decode shadow the first active group (same ring, same state): the wave stays in lock step
+    const uint64_t onmask = __builtin_amdgcn_ballot_w64(stream_on);
+    const int src = (stream_on || !onmask) ? lane : (int)__builtin_ctzll(onmask);
+    RiceCfg mc;
+    mc.kmod = mirror_i(rc.kmod, src);
+    mc.kmask = (1u << mc.kmod) - 1u;
+    mc.hist_mult = mirror_i(rc.hist_mult, src);
+    mc.rss = mirror_i(rc.rss, src);
+    const int n_eff = mirror_i(m.n, src);
+    const int ih = mirror_i(init_hist, src);
+    const uint32_t sb = (uint32_t)mirror_i((int)startbit, src);
+    const uint32_t* mringp = sh.rings[mirror_i(g, src)];
+    const uint32_t mring = lds_addr(mringp);
+    const int nmin = onmask ? __builtin_amdgcn_readfirstlane(-wave_max(-n_eff)) : 0;
+    const int nmax = __builtin_amdgcn_readfirstlane(wave_max(n_row));
+    if (nmax > 0) {
+        rice_init<LPS>(rs, filled, sb, ih, sh.rings[g], m.base, m.limit, sub, stream_on);
+        if (!stream_on) {
+            const uint32_t d0 = rs.next - 12u;
+            rs.w0 = mringp[(d0 & RING_MASK) >> 2];
+            rs.w1 = mringp[((d0 + 4u) & RING_MASK) >> 2];
+            rs.w2 = mringp[((d0 + 8u) & RING_MASK) >> 2];
+            rs.cur = rice_cursor((int)(rs.cur & 31u), mring | ((d0 + 8u) & RING_MASK));
+            rs.ra = rs.ra_sync = mring | ((d0 + 8u) & RING_MASK);
+        }
+    }
+    for (int c = 0; c < nchunks; c++) {
+        const int i0 = c * CHUNK;
+        int* q = (sub == 0) ? &sh.resq[c & 1][0][g] : &sh.dummy[lane];
+        if (i0 < nmax) {
+            const bool fast_chunk = i0 + CHUNK <= nmin - 1;
+            RingPrefetch<LPS> pf;
+            pf.cnt = 0;
+            if (fast_chunk) {
+                ring_prefetch_issue<LPS>(pf, filled, rs.next, m.base, m.limit, sub, stream_on && i0 + CHUNK < n_row);
+                for (int u = 0; u < CHUNK; u += SPEC_UNIT) {
+                    const bool redo = !spec_unit<true, S, true>(rs, full_left, mc, mring, q + u * S);
+                    if (redo) {
+                        for (int ii = 0; ii < SPEC_UNIT; ii++)
+                            q[(u + ii) * S] = ab_zigzag(rice_step(rs, mc, n_eff - 1 - (i0 + u + ii), i0 + u + ii, &flags, mring));
+                    }
+                }
+            } else {
+                const int qstride = (sub == 0) ? S : 0;
+                for (int ii = 0; ii < CHUNK; ii++) {
+                    const int i = i0 + ii;
+                    int r = 0;
+                    if (i < n_row) r = ab_zigzag(rice_step(rs, mc, n_row - 1 - i, i, &flags, mring));
+                    q[ii * qstride] = r;
+                }
+            }
+            wave_sync();
+            rice_sync(rs);
+            if (fast_chunk) ring_prefetch_commit<LPS>(pf, sh.rings[g], filled, sub);
+            else ring_fill<LPS>(sh.rings[g], filled, rs.next, m.base, m.limit, sub, stream_on && i0 + CHUNK < n_row);
+        }
+        const unsigned long long tb = p.dbg ? clock64() : 0;
+        wg_sync();  // chunk c is ready for the FIR wave
+        if (p.dbg && lane == 0) p.dbg[8 * blockIdx.x + 3] += clock64() - tb;   // diagnostic: time spent in barriers
+    }
+    wg_sync();      // final barrier of the pass (every wave executes nchunks + 1 per pass)
+    rice_sync(rs);
+    *flags_out = stream_on ? flags : 0;
+    return rice_bitpos(rs);
+}
+
+__device__ void ab_entropy_wave(const alac_decode_params& p, uint32_t pkt0, int lane, SplitShared<2>& sh, int nch0, int nch1) {
+    const int g = lane >> 3, sub = lane & 7;
+    const uint32_t pkt = pkt0 + (uint32_t)g;
+    const bool valid = pkt < p.n_packets;
+    alacgpu_cfg_dev cfg;
+    const Meta m = parse_meta(p, pkt, 0, valid, cfg);
+    const Meta mb = parse_meta(p, pkt, 1, valid, cfg);
+    if (valid && sub == 0) {
+        if (p.out_bytes) p.out_bytes[pkt] = m.out_bytes;
+        if (p.out_samples) p.out_samples[pkt] = m.n;
+    }
+    const bool compressed = valid && m.status == 0 && !m.esc;
+    RiceCfg rc;
+    rc.kmod = cfg.rice_kmodifier;
+    rc.kmask = (1u << cfg.rice_kmodifier) - 1u;
+    rc.hist_mult = m.ricemod * (cfg.rice_history_mult / 4);
+    rc.rss = m.rss;
+    int flags_a = 0, flags_b = 0;
+    uint32_t end_a = m.ricebit, end_b = m.ricebit;
+    end_a = ab_entropy_pass(p, sh, m, rc, cfg.rice_initial_history, m.ricebit, compressed, g, sub, lane, nch0, &flags_a);
+    end_b = end_a;
+    if (p.dbg && lane == 0) p.dbg[8 * blockIdx.x + 1] = clock64();
+    if (nch1 > 0) {
+        rc.hist_mult = mb.ricemod * (cfg.rice_history_mult / 4);
+        end_b = ab_entropy_pass(p, sh, m, rc, cfg.rice_initial_history, end_a, compressed && m.stereo, g, sub, lane, nch1, &flags_b);
+    }
+    // ---- status, in the reference's control-flow order (same as the other kernels / the oracle) ----
+    if (valid && sub == 0) {
+        int st = m.status;
+        if (st == 0 && !m.esc) {
+            const int nch = m.stereo ? 2 : 1;
+            for (int c = 0; c < nch && st == 0; c++) {
+                const int fl = c == 0 ? flags_a : flags_b;
+                const int pt = c == 0 ? m.predtype : mb.predtype;
+                const int Nc = c == 0 ? m.N : mb.N;
+                if (fl & 1) st = ALACGPU_ST_OVERRUN_D;
+                else if (fl & 2) st = ALACGPU_ST_UNSUPPORTED_PARAMS_D;
+                else if (pt != 0) st = ALACGPU_ST_UNSUPPORTED_PREDTYPE_D;
+                else if (Nc == 0 && m.n > 4096) st = ALACGPU_ST_REF_THROWS_D;
+            }
+            const uint32_t last = m.stereo ? end_b : end_a;
+            if (st == 0 && last > m.size_bits_end) st = ALACGPU_ST_OVERRUN_D;
+        } else if (st == 0 && m.esc) {
+            const uint32_t last = m.rawbit + (uint32_t)(m.n * (m.stereo ? 2 : 1) * m.ss);
+            if (last > m.size_bits_end) st = ALACGPU_ST_OVERRUN_D;
+        }
+        p.status[pkt] = st;
+    }
+}
+
+// FIR wave: the P8 layout of recon8_wave with the 8 rows' two parities holding the SAME channel of 8 different packets.
+__device__ void ab_fir_wave(const alac_decode_params& p, uint32_t pkt0, int lane, SplitShared<2>& sh, int ph, int nchunks) {
+    constexpr int S = 8;
+    const int row = lane >> 4, l = lane & 15, par = l & 1, j = l >> 1;
+    const int g = 2 * row + par;
+    const uint32_t pkt = pkt0 + (uint32_t)g;
+    const bool valid = pkt < p.n_packets;
+    alacgpu_cfg_dev cfg;
+    const Meta m = parse_meta(p, pkt, ph, valid, cfg);
+    const bool stream_on = valid && m.status == 0 && !m.esc && (ph == 0 || m.stereo);
+    const int n_row = stream_on ? m.n : 0;
+    Fir8Lane f;
+    f.hist = 0;
+    f.coef = (stream_on && j < m.N) ? (int)(int16_t)peek_bits(m.base, m.limit, m.coefbit + 16u * j, 16) : 0;
+    f.base = 0;
+    f.prev = 0;
+    f.q = stream_on ? m.q : 1;
+    f.rnd = stream_on ? m.rnd : 0;
+    f.rss = stream_on ? m.rss : 16;
+    f.qmask = (1 << f.q) - 1;
+    f.N = stream_on ? m.N : 0;
+    const bool tap = stream_on && j < m.N;
+    f.tlo = tap ? -1 : 0;
+    f.thi = tap ? 1 : 0;
+    f.w = tap ? (uint32_t)(m.N - j) : 0u;
+    f.bpaddr = ((lane & 48) + 2 * (stream_on ? (m.N - 1) & 7 : 0) + par) * 4;
+    const int nmax = __builtin_amdgcn_readfirstlane(wave_max(n_row));
+    const int nmin = __builtin_amdgcn_readfirstlane(-wave_max(stream_on ? -m.n : -0x7FFFFFFF));
+    const int* qzero = &sh.zeros[0][g];
+    for (int c = 0; c < nchunks; c++) {
+        const int i0 = c * CHUNK;
+        const unsigned long long tb = p.dbg ? clock64() : 0;
+        wg_sync();  // wait for chunk c
+        if (p.dbg && lane == 0 && c > 0) p.dbg[8 * blockIdx.x + 7] += clock64() - tb;   // diagnostic: time spent in barriers
+        const int* q = stream_on ? &sh.resq[c & 1][0][g] : qzero;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const int ih = i0 + 8 * half;
+            if (ih < nmax) {
+                if (ih > 8 && ih + 8 <= nmin) {
+                    int err = q[(8 * half) * S];
+#pragma unroll
+                    for (int ii = 0; ii < 8; ii++) {
+                        const int en = q[(8 * half + (ii < 7 ? ii + 1 : ii)) * S];
+                        fir8_step<false, true>(f, err, ih + ii, true);
+                        err = en;
+                    }
+                } else {
+                    for (int ii = 0; ii < 8; ii++) {
+                        const int i = ih + ii;
+                        const int err = q[(8 * half + ii) * S];
+                        fir8_step<true, true>(f, err, i, i < n_row);
+                    }
+                }
+            }
+            sh.outq[c & 1][half][0][lane] = f.hist;
+        }
+    }
+    wg_sync();  // final barrier of the pass
+}
+
+// 24-bit streams: merge the sample's shift bytes (AlacFile.cs:390-395) and sign-extend to 24 bits (:555-557).
+__device__ __forceinline__ int ab_finish24(const Meta& m, int val, int i, int chan) {
+    if (m.ss != 24) return val;
+    if (m.ub != 0 && !m.esc) {
+        const uint32_t bp = m.ubit + (uint32_t)((i * (m.stereo ? 2 : 1) + chan) * 8 * m.ub);
+        val = (int)(((uint32_t)val << (8 * m.ub)) | peek_bits(m.base, m.limit, bp, 8 * m.ub));
+    }
+    return __builtin_amdgcn_sbfe(val, 0, 24);
+}
+
+__device__ void ab_output_wave(const alac_decode_params& p, uint32_t pkt0, int lane, SplitShared<2>& sh, int nch0, int nch1) {
+    const int row = lane >> 4, l = lane & 15, par = l & 1, j = l >> 1;
+    const int g = 2 * row + par;
+    const uint32_t pkt = pkt0 + (uint32_t)g;
+    const bool valid = pkt < p.n_packets;
+    alacgpu_cfg_dev cfg;
+    const Meta m = parse_meta(p, pkt, 0, valid, cfg);
+    const int n_out = (valid && m.status == 0) ? m.n : 0;
+    const bool two_pass = n_out > 0 && m.stereo && !m.esc;   // A is parked in pass 0 and finished in pass 1
+    int32_t* pcm_slot = p.pcm_out + (int64_t)pkt * p.slot_ints;
+    int32_t* park = pcm_slot + m.n;
+    // ---- pass 0 ----
+    for (int c = 0; c <= nch0; c++) {
+        wg_sync();  // barrier c: chunk c-1's outputs are in the queue
+        if (c == 0) continue;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const int ih = (c - 1) * CHUNK + 8 * half;
+            const int cnt = min(8, n_out - ih);
+            if (j >= cnt) continue;
+            const int mine = sh.outq[(c - 1) & 1][half][0][lane];   // lane (2t + par) holds out[last - t] of its stream
+            if (m.esc) {                                            // uncompressed: raw samples, both channels now
+                const int i = ih + j;
+                const int nch = m.stereo ? 2 : 1;
+                for (int ch = 0; ch < nch; ch++) {
+                    const uint32_t bp = m.rawbit + (uint32_t)((i * nch + ch) * m.ss);
+                    int val = __builtin_amdgcn_sbfe((int)peek_bits(m.base, m.limit, bp, m.ss), 0, m.ss);
+                    if (m.ss == 24) val = __builtin_amdgcn_sbfe(val, 0, 24);
+                    if (ch < m.nc) store_sample(p, m, pcm_slot, (int64_t)i * m.nc + ch, val);
+                }
+                if (!m.stereo && m.nc > 1) store_sample(p, m, pcm_slot, (int64_t)i * m.nc + 1, 0);
+            } else {
+                const int i = ih + cnt - 1 - j;
+                if (two_pass) {
+                    park[i] = mine;
+                } else {                                            // one channel: done
+                    store_sample(p, m, pcm_slot, (int64_t)i * m.nc, ab_finish24(m, mine, i, 0));
+                    if (m.nc > 1) store_sample(p, m, pcm_slot, (int64_t)i * m.nc + 1, 0);
+                }
+            }
+        }
+    }
+    if (nch1 == 0) return;
+    // ---- pass 1: B arrives, A comes back from its parking place (loaded one chunk ahead) ----
+    int a_next[2] = {0, 0};
+    for (int c = 0; c <= nch1; c++) {
+        wg_sync();
+        int a_cur[2] = {a_next[0], a_next[1]};
+#pragma unroll
+        for (int half = 0; half < 2; half++) {                      // A for chunk c (used after the next barrier)
+            const int ih = c * CHUNK + 8 * half;
+            const int cnt = min(8, n_out - ih);
+            a_next[half] = (two_pass && c < nch1 && j < cnt) ? park[ih + cnt - 1 - j] : 0;
+        }
+        if (c == 0) continue;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const int ih = (c - 1) * CHUNK + 8 * half;
+            const int cnt = min(8, n_out - ih);
+            if (!two_pass || j >= cnt) continue;
+            const int i = ih + cnt - 1 - j;
+            const int a = a_cur[half], b = sh.outq[(c - 1) & 1][half][0][lane];
+            int left, right;
+            if (m.mixweight != 0) {                                 // AlacFile.cs:346-357 / :377-388
+                right = wsub(a, wmul(b, m.mixweight) >> (m.mixshift & 31));
+                left = wadd(right, b);
+            } else {
+                left = a;
+                right = b;
+            }
+            store_sample(p, m, pcm_slot, (int64_t)i * m.nc, ab_finish24(m, left, i, 0));
+            if (m.nc > 1) store_sample(p, m, pcm_slot, (int64_t)i * m.nc + 1, ab_finish24(m, right, i, 1));
+        }
+    }
+}
+
+__device__ __forceinline__ void ab_kernel_body(const alac_decode_params& p) {
+    __shared__ __attribute__((aligned(1024))) SplitShared<2> sh;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t pkt0 = blockIdx.x * (uint32_t)AB_PPW;
+    // every wave reads all 8 headers: pass lengths (uniform over the workgroup) and whether the P8 layout fits
+    int n0 = 0, n1 = 0;
+    bool bad = false;
+    {
+        const uint32_t pk = pkt0 + (uint32_t)(lane & 7);
+        const bool v = pk < p.n_packets;
+        alacgpu_cfg_dev c;
+        const Meta ma = parse_meta(p, pk, 0, v, c);
+        const Meta mb = parse_meta(p, pk, 1, v, c);
+        const bool ok = v && ma.status == 0;
+        n0 = ok ? ma.n : 0;
+        n1 = (ok && !ma.esc && ma.stereo) ? ma.n : 0;
+        bad = ok && !ma.esc && (ma.N < 1 || ma.N > 8 || (ma.stereo && (mb.N < 1 || mb.N > 8)));
+        // the parking place needs two ints per sample in the slot (always true for a two-channel stream cfg)
+        bad = bad || (n1 > 0 && (uint64_t)2 * (uint64_t)ma.n > p.slot_ints);
+    }
+    const bool fallback = __builtin_amdgcn_ballot_w64(bad) != 0;
+    if (p.ab_flags && threadIdx.x == 0) p.ab_flags[blockIdx.x] = fallback ? 1u : 0u;
+    if (fallback) return;
+    const int nch0 = (__builtin_amdgcn_readfirstlane(wave_max(n0)) + CHUNK - 1) / CHUNK;
+    const int nch1 = (__builtin_amdgcn_readfirstlane(wave_max(n1)) + CHUNK - 1) / CHUNK;
+    for (int t = threadIdx.x; t < CHUNK * 8; t += blockDim.x) (&sh.zeros[0][0])[t] = 0;
+    if (p.dbg && lane == 0) {   // diagnostic (ALACGPU_DEBUG_STAMPS): where each wave runs, when the workgroup starts
+        const unsigned hw = __builtin_amdgcn_s_getreg(63492), xcc = __builtin_amdgcn_s_getreg(63508);
+        p.dbg[8 * blockIdx.x + 4 + wave] = ((unsigned long long)xcc << 32) | hw;
+        if (wave == 0) p.dbg[8 * blockIdx.x + 0] = clock64();
+    }
+    wg_sync();
+    if (wave == 0) {
+        __builtin_amdgcn_s_setprio(ALAC_ENTROPY_PRIO);
+        ab_entropy_wave(p, pkt0, lane, sh, nch0, nch1);
+        if (p.dbg && lane == 0) p.dbg[8 * blockIdx.x + 2] = clock64();
+    } else if (wave == 1) {
+        ab_output_wave(p, pkt0, lane, sh, nch0, nch1);
+    } else {
+        ab_fir_wave(p, pkt0, lane, sh, 0, nch0);
+        if (nch1 > 0) ab_fir_wave(p, pkt0, lane, sh, 1, nch1);
+    }
+}
+
 }  // namespace
 
 // The 4- and 8-wave-per-workgroup kernels serve big batches, where exactly-full occupancy is a cliff (a
 // workgroup that does not fit waits for a whole round): cap them at 80 VGPRs = 6 waves per SIMD.  The small-batch
 // kernels never fill the CU and keep the unconstrained allocation.
+extern "C" __global__ __launch_bounds__(192) void alac_decode_ab_kernel(alac_decode_params p) { ab_kernel_body(p); }
 extern "C" __global__ __launch_bounds__(128) void alac_decode_split1_kernel(alac_decode_params p) { split_kernel_body<1, false>(p); }
 extern "C" __global__ __launch_bounds__(192) void alac_decode_split2_kernel(alac_decode_params p) { split_kernel_body<2, false>(p); }
 extern "C" __global__ __launch_bounds__(320, 6) void alac_decode_split4_kernel(alac_decode_params p) { split_kernel_body<4, false>(p); }

@@ -24,7 +24,9 @@ struct alacgpu_ctx {
     bool timed = false;
     uint32_t out_format = 0;           // 0 int32 per sample, 1 packed little-endian PCM
     bool all_mono = false;             // every stream cfg has one channel -> the *_mono kernels
-    int variant = 0;                   // 0 auto, 1 fused (v1), 2/3/4 split with 1/2/4 reconstruction waves
+    int variant = 0;                   // 0 auto, 1 fused (v1), 2/3/4 split with 1/2/4 reconstruction waves, 5 two-pass
+    uint32_t* d_ab_flags = nullptr;    // two-pass kernel -> fallback launch protocol (one flag per 8 packets), grow-only
+    size_t ab_flags_n = 0;
     // grow-only device workspace for the host-buffer entry points
     void* d_ws = nullptr;
     size_t ws_bytes = 0;
@@ -57,16 +59,38 @@ int ensure_ws(alacgpu_ctx* ctx, size_t bytes) {
     return ALACGPU_OK;
 }
 
-int launch(alacgpu_ctx* ctx, const alac_decode_params& p, hipStream_t stream) {
-    if (p.n_packets == 0) return ALACGPU_OK;
+int launch(alacgpu_ctx* ctx, const alac_decode_params& p_in, hipStream_t stream) {
+    if (p_in.n_packets == 0) return ALACGPU_OK;
+    alac_decode_params p = p_in;
+    p.ab_flags = nullptr;
     int variant = ctx->variant;
-    // auto: while every workgroup is resident at once (up to ~5 per CU) the small workgroup (1 entropy + 2
-    // reconstruction waves: 4 stereo / 8 mono packets) has the shortest critical path; bigger batches are throughput
-    // bound and do better with twice the packets per workgroup (half as many entropy waves per packet).  Measured on
-    // MI355X, cfg2, small / big workgroup: 4096 packets 0.99 / 1.08 ms, 8192 packets 2.14 / 1.37 ms (49 Gsamples/s:
-    // 1024 big workgroups are exactly one resident round), 32768 packets 7.1 / 6.2 ms; mono cfg4: 8192 packets
-    // 0.67 / 0.69 ms, 16384 packets 1.60 / 0.99 ms.  (A 16-packet workgroup was never better and is gone.)
-    if (variant == 0) variant = p.n_packets > (ctx->all_mono ? 10240u : 5120u) ? 4 : 3;
+    // auto, two-channel stream cfgs: the two-pass kernel (no Rice pre-scan; cfg2 0.99 -> 0.8x ms), which decodes the
+    // groups of 8 packets whose streams fit its layout (LPC order 1..8) and flags the others for a split kernel
+    // launched right behind it on the same stream.
+    // auto, fallback and one-channel cfgs: while every workgroup is resident at once (up to ~5 per CU) the small
+    // workgroup (1 entropy + 2 reconstruction waves: 4 stereo / 8 mono packets) has the shortest critical path; bigger
+    // batches are throughput bound and do better with twice the packets per workgroup (half as many entropy waves
+    // per packet).  Measured on MI355X, cfg2, small / big workgroup: 4096 packets 0.99 / 1.08 ms, 8192 packets
+    // 2.14 / 1.37 ms, 32768 packets 7.1 / 6.2 ms; mono cfg4: 8192 packets 0.67 / 0.69 ms, 16384 packets 1.60 / 0.99 ms.
+    const int split_auto = p.n_packets > (ctx->all_mono ? 10240u : 5120u) ? 4 : 3;
+    if (variant == 0) variant = ctx->all_mono ? split_auto : 5;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
+    if (variant == 5) {
+        const size_t groups = ((size_t)p.n_packets + 7) / 8;
+        if (groups > ctx->ab_flags_n) {
+            if (ctx->d_ab_flags) (void)hipFree(ctx->d_ab_flags);
+            ctx->d_ab_flags = nullptr;
+            ctx->ab_flags_n = 0;
+            const size_t want = groups + groups / 4 + 64;
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->d_ab_flags, want * sizeof(uint32_t)));
+            ctx->ab_flags_n = want;
+        }
+        p.ab_flags = ctx->d_ab_flags;
+        alac_decode_params args = p;
+        void* kargs[] = {&args};
+        HIP_TRY(ctx, hipLaunchKernel((const void*)alac_decode_ab_kernel, dim3((uint32_t)groups), dim3(192), kargs, 0, stream));
+        variant = split_auto;   // the fallback for what it flagged
+    }
     // Pick the kernel and its geometry.
     const void* fn = nullptr;
     uint32_t ppw = 2, threads = 64;    // packets per workgroup, workgroup size
@@ -88,7 +112,6 @@ int launch(alacgpu_ctx* ctx, const alac_decode_params& p, hipStream_t stream) {
     // (Workgroup placement was checked with HW_ID stamps: a 1024-workgroup grid lands as exactly 4 per CU on all
     // 256 CUs, so no occupancy padding is needed to balance it.)
     const uint32_t dyn_lds = 0;
-    HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
     {
         alac_decode_params args = p;
         void* kargs[] = {&args};
@@ -167,7 +190,7 @@ int alacgpu_create(const alacgpu_cfg* cfgs, uint32_t n_cfgs, int device, alacgpu
     ctx->n_cfgs = n_cfgs;
     ctx->all_mono = true;
     for (uint32_t i = 0; i < n_cfgs; i++) ctx->all_mono = ctx->all_mono && cfgs[i].num_channels == 1;
-    if (const char* v = std::getenv("ALACGPU_KERNEL_VARIANT")) ctx->variant = std::atoi(v) >= 0 && std::atoi(v) <= 4 ? std::atoi(v) : 0;
+    if (const char* v = std::getenv("ALACGPU_KERNEL_VARIANT")) ctx->variant = std::atoi(v) >= 0 && std::atoi(v) <= 5 ? std::atoi(v) : 0;
     int rc = ALACGPU_OK;
     do {
         if (hipSetDevice(device) != hipSuccess) { rc = ALACGPU_ERR_NO_DEVICE; break; }
@@ -192,6 +215,7 @@ void alacgpu_destroy(alacgpu_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
+    if (ctx->d_ab_flags) (void)hipFree(ctx->d_ab_flags);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     if (ctx->d_cfgs) (void)hipFree(ctx->d_cfgs);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -390,7 +414,7 @@ int alacgpu_set_output_format(alacgpu_ctx* ctx, int format) {
 }
 
 int alacgpu_set_kernel_variant(alacgpu_ctx* ctx, int variant) {
-    if (!ctx || variant < 0 || variant > 4) return ALACGPU_ERR_BAD_ARG;
+    if (!ctx || variant < 0 || variant > 5) return ALACGPU_ERR_BAD_ARG;
     ctx->variant = variant;
     return ALACGPU_OK;
 }

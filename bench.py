@@ -34,7 +34,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=2, help="BASELINE.json config number (2..5)")
     ap.add_argument("--packets", type=int, default=None, help="packets per GPU (default: the config's batch)")
-    ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 auto, 1 fused, 2/3/4 split)")
+    ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 auto, 1 fused, 2/3/4 split, 5 two-pass)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-allgather", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 path)")
@@ -186,9 +186,10 @@ def main():
 
     if rank == 0:
         all_mono = all(c[5] == 1 for c in b["stream_cfgs"])
-        auto = 4 if n_packets > (10240 if all_mono else 5120) else 3   # mirrors the library's choice (alacgpu_api.hip: launch)
+        split_auto = 4 if n_packets > (10240 if all_mono else 5120) else 3
+        auto = split_auto if all_mono else 5           # mirrors the library's choice (alacgpu_api.hip: launch)
         kernel_name = {1: "alac_decode_packets_kernel", 2: "alac_decode_split1_kernel", 3: "alac_decode_split2_kernel",
-                       4: "alac_decode_split4_kernel"}[args.variant or auto]
+                       4: "alac_decode_split4_kernel", 5: "alac_decode_ab_kernel"}[args.variant or auto]
         if all_mono and (args.variant or auto) in (3, 4):
             kernel_name = kernel_name.replace("_kernel", "_mono_kernel")
         # HBM traffic comes from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read in-process):

@@ -129,8 +129,9 @@ enum { ALACGPU_OUT_INT32 = 0, ALACGPU_OUT_PACKED_LE = 1 };
 int alacgpu_set_output_format(alacgpu_ctx* ctx, int format);
 
 /* Tuning / A-B knob (no effect on results): 0 = auto (default), 1 = fused single-wave kernel,
- * 2 / 3 / 4 = split kernel with 1 / 2 / 4 reconstruction waves per workgroup.  Also settable with the
- * environment variable ALACGPU_KERNEL_VARIANT at create time. */
+ * 2 / 3 / 4 = split kernel with 1 / 2 / 4 reconstruction waves per workgroup, 5 = two-pass kernel (channel A, then
+ * channel B: no Rice pre-scan) with a split kernel behind it for the packets it does not take.  Also settable with
+ * the environment variable ALACGPU_KERNEL_VARIANT at create time. */
 int alacgpu_set_kernel_variant(alacgpu_ctx* ctx, int variant);
 
 const char* alacgpu_strerror(int rc);

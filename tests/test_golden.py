@@ -32,7 +32,7 @@ def test_oracle_reproduces_golden(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
 def test_gpu_reproduces_golden(variant):
     import alac.net_amd as pkg
 

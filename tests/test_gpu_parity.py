@@ -19,7 +19,7 @@ def pkg():
     return p
 
 
-VARIANTS = [1, 2, 3, 4]
+VARIANTS = [1, 2, 3, 4, 5]
 
 
 def run_both(pkg, oracle, b, n_threads=8, variant=0):
@@ -145,7 +145,7 @@ def _random_recipe_batch(synth, seed, count, stereo, is24):
     return d
 
 
-@pytest.mark.parametrize("variant", [1, 3, 4])
+@pytest.mark.parametrize("variant", [1, 3, 4, 5])
 @pytest.mark.parametrize("stereo,is24,loud", [(True, False, False), (True, True, True), (False, False, True), (False, True, False)])
 def test_random_recipes_vs_oracle(pkg, oracle, synth, variant, stereo, is24, loud):
     d = _random_recipe_batch(synth, 1234 + 2 * stereo + is24, 96, stereo, is24)
@@ -163,7 +163,7 @@ def test_random_recipes_vs_oracle(pkg, oracle, synth, variant, stereo, is24, lou
         assert np.array_equal(g[0][p, :cnt], b["pcm"][p, :cnt])
 
 
-@pytest.mark.parametrize("variant", [1, 3])
+@pytest.mark.parametrize("variant", [1, 3, 5])
 def test_exotic_stream_configs(pkg, oracle, synth, variant):
     # other rice parameters than the usual 40/10/14, several stream configs in one batch
     cfgs = [(4096, 16, 40, 10, 14, 2), (4096, 16, 255, 255, 16, 2), (4096, 16, 8, 0, 1, 2), (4096, 24, 100, 3, 9, 2)]
@@ -181,7 +181,7 @@ def test_exotic_stream_configs(pkg, oracle, synth, variant):
     assert_same(g, o, cfgs, ci)
 
 
-@pytest.mark.parametrize("variant", [1, 3])
+@pytest.mark.parametrize("variant", [1, 3, 5])
 def test_mutated_packets_never_hang_and_match(pkg, oracle, synth, variant):
     # flip bits in valid packets; every packet is followed by zero padding so that both decoders see
     # zeros past a (possibly now too short) packet.  The kernel must terminate and agree with the oracle
@@ -238,7 +238,7 @@ def test_auto_kernel_choice_above_the_big_batch_threshold(pkg, oracle, synth, st
     assert_same(g, o, cfgs, None)
 
 
-@pytest.mark.parametrize("variant", [1, 3, 4])
+@pytest.mark.parametrize("variant", [1, 3, 4, 5])
 def test_maximum_frame_length(pkg, oracle, synth, variant):
     # 16384 samples per channel is the reference's scratch size (AlacFile.cs:28): the longest frame it can decode.
     # 24-bit, shift bytes, order 16 and a hassize header: the ring and the bit cursor wrap many times
@@ -307,7 +307,7 @@ def test_cpp_host_mirror(pkg, oracle, synth, tmp_path):
     assert out.returncode == 1 and "FIXME: unimplemented sample size 20" in out.stdout
 
 
-@pytest.mark.parametrize("variant", [1, 3, 4])
+@pytest.mark.parametrize("variant", [1, 3, 4, 5])
 @pytest.mark.parametrize("cfg", [2, 3, 4, 5])
 def test_packed_output_equals_format_samples(pkg, oracle, synth, cfg, variant):
     # ALACGPU_OUT_PACKED_LE: the kernel stores what AlacContext.Read returns (FormatSamples fused, AlacContext.cs:214-256)
@@ -357,7 +357,7 @@ def test_host_path_reuses_the_callers_array_and_trims_the_packed_copy(pkg, oracl
         assert (raw[:, bps * slot:] == 0x5A).all()      # beyond what any packet of these cfgs can fill: untouched
 
 
-@pytest.mark.parametrize("variant", [3, 4])
+@pytest.mark.parametrize("variant", [3, 4, 5])
 @pytest.mark.parametrize("stereo,is24", [(True, False), (True, True), (False, False)])
 def test_p8_layout_random(pkg, oracle, synth, variant, stereo, is24):
     # every stream has 1 <= N <= 8, so the split kernels use the 8-lanes-per-stream reconstruction layout;

@@ -60,7 +60,7 @@ def main():
         o = orc.decode_batch(orc.make_cfgs(cfgs), b["blob"], b["offsets"], b["sizes"], None, b["slot_ints"], n_threads=8)
         assert (o[3] == 0).all(), o[3]
         with pkg.AlacGpuContext(cfgs) as ctx:
-            for variant in (1, 2, 3, 4):
+            for variant in (1, 2, 3, 4, 5):
                 ctx.set_kernel_variant(variant)
                 g = ctx.decode_batch(b["blob"], b["offsets"], b["sizes"], None, b["slot_ints"])
                 assert np.array_equal(g[3], o[3]) and np.array_equal(g[1], o[1]) and np.array_equal(g[2], o[2]), (rounds, variant)
@@ -72,7 +72,7 @@ def main():
                                          f"n {d['n'][p]} first bad index {bad[:5]}")
         rounds += 1
         packets += count
-    print(f"stress ok: {rounds} rounds, {packets} packets x 4 kernel variants, {time.time() - t0:.0f} s, seed {seed}, {skipped} recipes skipped")
+    print(f"stress ok: {rounds} rounds, {packets} packets x 5 kernel variants, {time.time() - t0:.0f} s, seed {seed}, {skipped} recipes skipped")
 
 
 if __name__ == "__main__":
