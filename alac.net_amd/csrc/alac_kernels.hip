@@ -919,13 +919,24 @@ __device__ __forceinline__ void split_kernel_body(const alac_decode_params& p) {
 // ===================================================================================================================
 constexpr int AB_PPW = 8;
 
+// The rings are topped up by the OUTPUT wave (which idles most of the time) instead of the entropy wave (which is the
+// critical one): the entropy wave publishes how far each stream has read, at every chunk barrier; the output wave then
+// loads the next 128 bytes of every stream that has room, swaps them and writes them into the ring before the next
+// barrier.  What it wrote after barrier c is read after barrier c+1 at the earliest; the ring is kept at least 880 bytes
+// ahead of the reader, who consumes at most 118 per chunk.
+struct AbShared : SplitShared<2> {
+    uint32_t ring_next[8];     // entropy wave -> output wave: Rice::next of the stream at the last barrier
+    uint32_t ring_filled[8];   // entropy wave -> output wave at the start of a pass: bytes staged by rice_init
+    uint32_t ring_on[8];       // stream switched on in this pass
+};
+
 // One entropy pass over stream `g` of every lane group (S = 8 streams, 8 lanes each): the main pass of entropy_wave.
 // Returns the bit position after the last symbol; *flags collects rice_step's flags.
 // The queue of this kernel carries the unsigned code value dv, not the residual (the FIR wave has the cycles to spare
 // and converts it, fir8_step<.., true>): the inverse of r = (dv >> 1) ^ -(dv & 1) for what rice_step hands back.
 __device__ __forceinline__ int ab_zigzag(int r) { return (int)(((uint32_t)r << 1) ^ (uint32_t)(r >> 31)); }
 
-__device__ uint32_t ab_entropy_pass(const alac_decode_params& p, SplitShared<2>& sh, const Meta& m, const RiceCfg& rc, int init_hist,
+__device__ uint32_t ab_entropy_pass(const alac_decode_params& p, AbShared& sh, const Meta& m, const RiceCfg& rc, int init_hist,
                                     uint32_t startbit, bool stream_on, int g, int sub, int lane, int nchunks, int* flags_out) {
     constexpr int S = 8, LPS = 8;
     const int n_row = stream_on ? m.n : 0;
@@ -962,15 +973,17 @@ __device__ uint32_t ab_entropy_pass(const alac_decode_params& p, SplitShared<2>&
             rs.ra = rs.ra_sync = mring | ((d0 + 8u) & RING_MASK);
         }
     }
+    if (sub == 0) {   // hand the ring over to the output wave (it reads this after the first barrier of the pass)
+        sh.ring_on[g] = stream_on ? 1u : 0u;
+        sh.ring_filled[g] = filled;
+        sh.ring_next[g] = rs.next;
+    }
     for (int c = 0; c < nchunks; c++) {
         const int i0 = c * CHUNK;
         int* q = (sub == 0) ? &sh.resq[c & 1][0][g] : &sh.dummy[lane];
         if (i0 < nmax) {
             const bool fast_chunk = i0 + CHUNK <= nmin - 1;
-            RingPrefetch<LPS> pf;
-            pf.cnt = 0;
             if (fast_chunk) {
-                ring_prefetch_issue<LPS>(pf, filled, rs.next, m.base, m.limit, sub, stream_on && i0 + CHUNK < n_row);
                 for (int u = 0; u < CHUNK; u += SPEC_UNIT) {
                     const bool redo = !spec_unit<true, S, true>(rs, full_left, mc, mring, q + u * S);
                     if (redo) {
@@ -987,10 +1000,8 @@ __device__ uint32_t ab_entropy_pass(const alac_decode_params& p, SplitShared<2>&
                     q[ii * qstride] = r;
                 }
             }
-            wave_sync();
             rice_sync(rs);
-            if (fast_chunk) ring_prefetch_commit<LPS>(pf, sh.rings[g], filled, sub);
-            else ring_fill<LPS>(sh.rings[g], filled, rs.next, m.base, m.limit, sub, stream_on && i0 + CHUNK < n_row);
+            if (sub == 0) sh.ring_next[g] = rs.next;
         }
         const unsigned long long tb = p.dbg ? clock64() : 0;
         wg_sync();  // chunk c is ready for the FIR wave
@@ -1002,7 +1013,7 @@ __device__ uint32_t ab_entropy_pass(const alac_decode_params& p, SplitShared<2>&
     return rice_bitpos(rs);
 }
 
-__device__ void ab_entropy_wave(const alac_decode_params& p, uint32_t pkt0, int lane, SplitShared<2>& sh, int nch0, int nch1) {
+__device__ void ab_entropy_wave(const alac_decode_params& p, uint32_t pkt0, int lane, AbShared& sh, int nch0, int nch1) {
     const int g = lane >> 3, sub = lane & 7;
     const uint32_t pkt = pkt0 + (uint32_t)g;
     const bool valid = pkt < p.n_packets;
@@ -1053,7 +1064,7 @@ __device__ void ab_entropy_wave(const alac_decode_params& p, uint32_t pkt0, int 
 }
 
 // FIR wave: the P8 layout of recon8_wave with the 8 rows' two parities holding the SAME channel of 8 different packets.
-__device__ void ab_fir_wave(const alac_decode_params& p, uint32_t pkt0, int lane, SplitShared<2>& sh, int ph, int nchunks) {
+__device__ void ab_fir_wave(const alac_decode_params& p, uint32_t pkt0, int lane, AbShared& sh, int ph, int nchunks) {
     constexpr int S = 8;
     const int row = lane >> 4, l = lane & 15, par = l & 1, j = l >> 1;
     const int g = 2 * row + par;
@@ -1123,7 +1134,63 @@ __device__ __forceinline__ int ab_finish24(const Meta& m, int val, int i, int ch
     return __builtin_amdgcn_sbfe(val, 0, 24);
 }
 
-__device__ void ab_output_wave(const alac_decode_params& p, uint32_t pkt0, int lane, SplitShared<2>& sh, int nch0, int nch1) {
+// Ring refill service of the output wave (see AbShared): lane group r = lane >> 3 serves stream r, 16 bytes per lane.
+struct AbRefill {
+    static constexpr int ROUNDS = 2;           // up to 256 bytes per stream per chunk (a chunk consumes at most 118)
+    const uint8_t* base;
+    int64_t limit;
+    AbShared& sh;
+    uint32_t* ring;
+    int r, sub;
+    uint32_t filled = 0, cnt = 0;
+    uint4 v[ROUNDS];
+    __device__ AbRefill(const alac_decode_params& p, uint32_t pkt0, int lane, AbShared& sh_) : sh(sh_) {
+        r = lane >> 3;
+        sub = lane & 7;
+        ring = sh.rings[r];
+        const uint32_t pk = pkt0 + (uint32_t)r;
+        base = p.blob;
+        limit = 0;
+        if (pk < p.n_packets) {                // as parse_meta: 16-byte aligned-down packet start, readable bytes from it
+            const uint64_t off = p.offsets[pk];
+            const uint64_t al = off - (off & 15u);
+            base = p.blob + al;
+            limit = (int64_t)p.blob_limit - (int64_t)al;
+        }
+    }
+    // after a barrier: look at how far the stream has read and load what fits (first: a pass starts, take over `filled`)
+    __device__ void issue(bool first) {
+        if (first) filled = sh.ring_filled[r];
+        const uint32_t next = sh.ring_next[r];
+        const bool on = sh.ring_on[r] != 0;
+        cnt = 0;
+#pragma unroll
+        for (int k = 0; k < ROUNDS; k++) {
+            v[k] = make_uint4(0, 0, 0, 0);
+            if (on && filled + (uint32_t)(k + 1) * 128u <= (next - 12u) + RING_BYTES) {
+                const int64_t off = (int64_t)filled + (int64_t)k * 128 + sub * 16;
+                if (off + 16 <= limit) v[k] = *reinterpret_cast<const uint4*>(base + off);
+                cnt = (uint32_t)(k + 1);
+            }
+        }
+    }
+    // before the next barrier: byte-swap into the ring
+    __device__ void commit() {
+#pragma unroll
+        for (int k = 0; k < ROUNDS; k++) {
+            if ((uint32_t)k < cnt) {
+                const uint32_t off = filled + (uint32_t)k * 128u + (uint32_t)sub * 16u;
+                uint4 w = v[k];
+                asm volatile("" : "+v"(w.x), "+v"(w.y), "+v"(w.z), "+v"(w.w));   // keep the swap (and the wait for the load) here
+                *reinterpret_cast<uint4*>(&ring[(off & RING_MASK) >> 2]) =
+                    make_uint4(__builtin_bswap32(w.x), __builtin_bswap32(w.y), __builtin_bswap32(w.z), __builtin_bswap32(w.w));
+            }
+        }
+        filled += cnt * 128u;
+    }
+};
+
+__device__ void ab_output_wave(const alac_decode_params& p, uint32_t pkt0, int lane, AbShared& sh, int nch0, int nch1) {
     const int row = lane >> 4, l = lane & 15, par = l & 1, j = l >> 1;
     const int g = 2 * row + par;
     const uint32_t pkt = pkt0 + (uint32_t)g;
@@ -1134,10 +1201,12 @@ __device__ void ab_output_wave(const alac_decode_params& p, uint32_t pkt0, int l
     const bool two_pass = n_out > 0 && m.stereo && !m.esc;   // A is parked in pass 0 and finished in pass 1
     int32_t* pcm_slot = p.pcm_out + (int64_t)pkt * p.slot_ints;
     int32_t* park = pcm_slot + m.n;
+    AbRefill rf(p, pkt0, lane, sh);
     // ---- pass 0 ----
     for (int c = 0; c <= nch0; c++) {
         wg_sync();  // barrier c: chunk c-1's outputs are in the queue
-        if (c == 0) continue;
+        if (c < nch0) rf.issue(c == 0);
+        if (c == 0) { rf.commit(); continue; }
 #pragma unroll
         for (int half = 0; half < 2; half++) {
             const int ih = (c - 1) * CHUNK + 8 * half;
@@ -1164,12 +1233,14 @@ __device__ void ab_output_wave(const alac_decode_params& p, uint32_t pkt0, int l
                 }
             }
         }
+        if (c < nch0) rf.commit();
     }
     if (nch1 == 0) return;
     // ---- pass 1: B arrives, A comes back from its parking place (loaded one chunk ahead) ----
     int a_next[2] = {0, 0};
     for (int c = 0; c <= nch1; c++) {
         wg_sync();
+        if (c < nch1) rf.issue(c == 0);
         int a_cur[2] = {a_next[0], a_next[1]};
 #pragma unroll
         for (int half = 0; half < 2; half++) {                      // A for chunk c (used after the next barrier)
@@ -1177,7 +1248,7 @@ __device__ void ab_output_wave(const alac_decode_params& p, uint32_t pkt0, int l
             const int cnt = min(8, n_out - ih);
             a_next[half] = (two_pass && c < nch1 && j < cnt) ? park[ih + cnt - 1 - j] : 0;
         }
-        if (c == 0) continue;
+        if (c == 0) { rf.commit(); continue; }
 #pragma unroll
         for (int half = 0; half < 2; half++) {
             const int ih = (c - 1) * CHUNK + 8 * half;
@@ -1196,11 +1267,12 @@ __device__ void ab_output_wave(const alac_decode_params& p, uint32_t pkt0, int l
             store_sample(p, m, pcm_slot, (int64_t)i * m.nc, ab_finish24(m, left, i, 0));
             if (m.nc > 1) store_sample(p, m, pcm_slot, (int64_t)i * m.nc + 1, ab_finish24(m, right, i, 1));
         }
+        if (c < nch1) rf.commit();
     }
 }
 
 __device__ __forceinline__ void ab_kernel_body(const alac_decode_params& p) {
-    __shared__ __attribute__((aligned(1024))) SplitShared<2> sh;
+    __shared__ __attribute__((aligned(1024))) AbShared sh;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t pkt0 = blockIdx.x * (uint32_t)AB_PPW;
     // every wave reads all 8 headers: pass lengths (uniform over the workgroup) and whether the P8 layout fits
