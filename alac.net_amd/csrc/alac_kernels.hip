@@ -984,6 +984,7 @@ __device__ uint32_t ab_entropy_pass(const alac_decode_params& p, AbShared& sh, c
         if (i0 < nmax) {
             const bool fast_chunk = i0 + CHUNK <= nmin - 1;
             if (fast_chunk) {
+#pragma unroll
                 for (int u = 0; u < CHUNK; u += SPEC_UNIT) {
                     const bool redo = !spec_unit<true, S, true>(rs, full_left, mc, mring, q + u * S);
                     if (redo) {
