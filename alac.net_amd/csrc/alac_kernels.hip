@@ -1004,9 +1004,7 @@ __device__ uint32_t ab_entropy_pass(const alac_decode_params& p, AbShared& sh, c
             rice_sync(rs);
             if (sub == 0) sh.ring_next[g] = rs.next;
         }
-        const unsigned long long tb = p.dbg ? clock64() : 0;
         wg_sync();  // chunk c is ready for the FIR wave
-        if (p.dbg && lane == 0) p.dbg[8 * blockIdx.x + 3] += clock64() - tb;   // diagnostic: time spent in barriers
     }
     wg_sync();      // final barrier of the pass (every wave executes nchunks + 1 per pass)
     rice_sync(rs);
@@ -1300,8 +1298,10 @@ __device__ __forceinline__ void ab_kernel_body(const alac_decode_params& p) {
     for (int t = threadIdx.x; t < CHUNK * 8; t += blockDim.x) (&sh.zeros[0][0])[t] = 0;
     if (p.dbg && lane == 0) {   // diagnostic (ALACGPU_DEBUG_STAMPS): where each wave runs, when the workgroup starts
         const unsigned hw = __builtin_amdgcn_s_getreg(63492), xcc = __builtin_amdgcn_s_getreg(63508);
-        p.dbg[8 * blockIdx.x + 4 + wave] = ((unsigned long long)xcc << 32) | hw;
-        if (wave == 0) p.dbg[8 * blockIdx.x + 0] = clock64();
+        if (wave == 0) {
+            p.dbg[8 * blockIdx.x + 4] = ((unsigned long long)xcc << 32) | hw;
+            p.dbg[8 * blockIdx.x + 0] = clock64();
+        }
     }
     wg_sync();
     if (wave == 0) {
