@@ -22,11 +22,15 @@ shutil.copy(newest(f"{src}/stats/*/*_kernel_stats.csv"), f"profiles/{tag}_kernel
 summary = {}
 kernel = None
 for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
-    rows = list(csv.DictReader(open(newest(f"{src}/{d}/*/*_counter_collection.csv"))))
+    rows = [r for r in csv.DictReader(open(newest(f"{src}/{d}/*/*_counter_collection.csv"))) if "alac" in r["Kernel_Name"]]
+    # a launch may be two kernels (the two-pass kernel and its fallback): report the one that does the work
+    tot = collections.Counter()
+    for r in rows:
+        tot[r["Kernel_Name"]] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    kernel = tot.most_common(1)[0][0]
     agg, dur = collections.defaultdict(list), []
     for r in rows:
-        if "alac" in r["Kernel_Name"]:
-            kernel = r["Kernel_Name"]
+        if r["Kernel_Name"] == kernel:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
             dur.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     summary[d] = {"kernel": kernel, "avg_kernel_ns": sum(dur) / len(dur),
@@ -47,9 +51,10 @@ out = {
         "read_bytes_per_launch": 2 * fetch_kb * 1024, "write_bytes_per_launch": write_kb * 1024,
         "hbm_bytes_per_launch": 2 * fetch_kb * 1024 + write_kb * 1024,
         "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
-        "note": "reads are ~1.6x the packet bytes: the A stream of every stereo packet is read twice (pre-scan + main pass); the"
-                " 45 MB input blob stays cache resident across the repeated bench steps, so the read side is an upper bound on HBM"
-                " reads; writes equal the PCM bytes exactly",
+        "note": "two-pass kernel: pass 0 parks channel A's reconstructed samples in the upper half of the packet's output slot"
+                " (4 bytes per sample frame: 67 MB for cfg2) and pass 1 reads them back: writes = PCM (134 MB) + parked (67 MB),"
+                " reads = packet bytes (45 MB, cache resident across the repeated bench steps) + parked (67 MB).  That round trip"
+                " replaces the Rice-only pre-scan of channel A; at 0.87 ms per launch the 320 MB are 4.6 % of the HBM peak\n",
     },
     "effective_clock_GHz": gui / 8 / summary["pmc_write"]["avg_kernel_ns"],
 }
