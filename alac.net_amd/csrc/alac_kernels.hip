@@ -6,9 +6,12 @@
 // :256-336 = predictor_decompress_fir_adapt) and mid/side un-mixing + store (Deinterlace16/24
 // :338-421), integer only, bit-exact with the reference's C# int semantics.
 //
-// Two kernel families live here:
-//   v2 "split" (default; further down): per workgroup one entropy wave (pre-scan + Rice -> LDS residual queue)
-//       and reconstruction waves (FIR, un-mix, store), pipelined by one s_barrier per 16 samples;
+// Three kernel families live here:
+//   v3 "two-pass" (default for two-channel stream cfgs; last in the file): 8 packets per workgroup, channel A decoded
+//       for real in pass 0 (its end is where B starts: no pre-scan), parked, un-mixed with B in pass 1;
+//   v2 "split" (fallback of v3 for LPC orders above 8, default for one-channel cfgs): per workgroup one entropy wave
+//       (pre-scan + Rice -> LDS residual queue) and reconstruction waves (FIR, un-mix, store), pipelined by one
+//       s_barrier per 16 samples;
 //   v1 "fused" (first, below): every lane group runs Rice and FIR itself.  Simplest correct form and A/B baseline.
 //
 // Mapping of v1, "fused row-per-stream":
