@@ -330,6 +330,40 @@ def test_packed_output_equals_format_samples(pkg, oracle, synth, cfg, variant):
         assert np.array_equal(raw[p, : len(exp)], exp), f"packet {p}"
 
 
+@pytest.mark.parametrize("variant", [3, 5])
+@pytest.mark.parametrize("stereo", [True, False])
+def test_packed_24bit_low_order_streams(pkg, oracle, synth, variant, stereo):
+    # 24-bit, LPC orders 1..8 (the layout the two-pass kernel takes), shift bytes 0/1/2, packed output: the two-pass
+    # kernel parks channel A in the upper half of the slot while the packed bytes grow from its start
+    count = 40
+    rng = np.random.default_rng(77 + stereo)
+    d = synth.packet_descs(count, n=4096, max_samples_per_frame=4096, sample_size=24, stereo=int(stereo))
+    d["n"] = rng.integers(1, 4097, count)
+    d["n"][::3] = 4096
+    d["pred_order"] = rng.integers(1, 9, (count, 2))
+    d["ub"] = rng.integers(0, 3, count)
+    d["escape"] = rng.random(count) < 0.1
+    d["mix_shift"] = rng.integers(0, 5, count)
+    d["mix_weight"] = np.minimum(rng.integers(0, 8, count), 1 << d["mix_shift"].astype(np.int64))
+    sig = synth.default_signal(99)
+    sig["silence_prob"] = 0.3
+    b = synth.make_batch(d, sig, want_pcm=True)
+    scfg = [(4096, 24, 40, 10, 14, 2 if stereo else 1)]
+    cfgs = oracle.make_cfgs(scfg)
+    opcm, oob, oos, ost = oracle.decode_batch(cfgs, b["blob"], b["offsets"], b["sizes"], None, b["slot_ints"], n_threads=8)
+    assert (ost == 0).all()
+    with pkg.AlacGpuContext(scfg) as ctx:
+        ctx.set_kernel_variant(variant)
+        ctx.set_output_format(1)
+        pcm, ob, os_, st = ctx.decode_batch(b["blob"], b["offsets"], b["sizes"], None, b["slot_ints"])
+    assert np.array_equal(st, ost) and np.array_equal(ob, oob) and np.array_equal(os_, oos)
+    raw = pcm.view(np.uint8)
+    for p in range(count):
+        ref = oracle.expand_reference_layout(cfgs[0:1], opcm[p], int(oos[p]))
+        exp = oracle.format_samples(3, ref, int(oob[p]))
+        assert np.array_equal(raw[p, : len(exp)], exp), f"packet {p}"
+
+
 @pytest.mark.parametrize("cfg", [2, 3])
 def test_host_path_reuses_the_callers_array_and_trims_the_packed_copy(pkg, oracle, synth, cfg):
     # decode_batch(out=...) decodes into the caller's array (no fresh allocation); with packed output only the
