@@ -330,6 +330,42 @@ def test_packed_output_equals_format_samples(pkg, oracle, synth, cfg, variant):
         assert np.array_equal(raw[p, : len(exp)], exp), f"packet {p}"
 
 
+@pytest.mark.parametrize("out_format", [0, 1])
+def test_two_pass_kernel_and_its_fallback_share_a_batch(pkg, oracle, synth, out_format):
+    # groups of 8 packets alternate between what the two-pass kernel takes (orders 1..8) and what it hands to the split
+    # kernel behind it (order 16 somewhere in the group); one-channel, uncompressed and short packets mixed in; the last
+    # group is partly filled
+    count = 8 * 9 + 5
+    rng = np.random.default_rng(4711)
+    d = synth.packet_descs(count, n=2048, max_samples_per_frame=4096, sample_size=16, stereo=1)
+    d["n"] = rng.integers(1, 2049, count)
+    d["n"][::2] = 2048
+    d["pred_order"] = rng.integers(1, 9, (count, 2))
+    for g in range(1, 10, 2):                       # every other group: one packet with a long predictor
+        d["pred_order"][min(8 * g + int(rng.integers(0, 8)), count - 1), int(rng.integers(0, 2))] = 16
+    d["stereo"][rng.random(count) < 0.15] = 0       # channels field 0 in a two-channel file
+    d["escape"] = rng.random(count) < 0.1
+    sig = synth.default_signal(5)
+    sig["silence_prob"] = 0.3
+    b = synth.make_batch(d, sig, want_pcm=True)
+    scfg = [(4096, 16, 40, 10, 14, 2)]
+    cfgs = oracle.make_cfgs(scfg)
+    o = oracle.decode_batch(cfgs, b["blob"], b["offsets"], b["sizes"], None, b["slot_ints"], n_threads=8)
+    assert (o[3] == 0).all()
+    with pkg.AlacGpuContext(scfg) as ctx:           # auto: two-pass + fallback
+        ctx.set_output_format(out_format)
+        g = ctx.decode_batch(b["blob"], b["offsets"], b["sizes"], None, b["slot_ints"])
+    if out_format == 0:
+        assert_same(g, o, scfg, None)
+    else:
+        assert np.array_equal(g[3], o[3]) and np.array_equal(g[1], o[1]) and np.array_equal(g[2], o[2])
+        raw = g[0].view(np.uint8)
+        for p in range(count):
+            ref = oracle.expand_reference_layout(cfgs[0:1], o[0][p], int(o[2][p]))
+            exp = oracle.format_samples(2, ref, int(o[1][p]))
+            assert np.array_equal(raw[p, : len(exp)], exp), f"packet {p}"
+
+
 @pytest.mark.parametrize("variant", [3, 5])
 @pytest.mark.parametrize("stereo", [True, False])
 def test_packed_24bit_low_order_streams(pkg, oracle, synth, variant, stereo):
