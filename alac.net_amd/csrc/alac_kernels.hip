@@ -927,7 +927,16 @@ constexpr int AB_PPW = 8;
 // loads the next 128 bytes of every stream that has room, swaps them and writes them into the ring before the next
 // barrier.  What it wrote after barrier c is read after barrier c+1 at the earliest; the ring is kept at least 880 bytes
 // ahead of the reader, who consumes at most 118 per chunk.
-struct AbShared : SplitShared<2> {
+#ifndef ALAC_AB_CHUNK
+#define ALAC_AB_CHUNK 32
+#endif
+constexpr int AB_CHUNK = ALAC_AB_CHUNK;   // samples per barrier: twice the split kernels' (half the per-chunk overhead of the critical wave)
+struct AbShared {
+    uint32_t rings[8][RING_BYTES / 4];
+    int resq[2][AB_CHUNK][8];
+    int zeros[AB_CHUNK][8];    // residuals of a switched-off stream
+    int outq[2][AB_CHUNK / 8][64];   // FIR wave -> output wave, 8 outputs per stream per 8 samples
+    int dummy[AB_CHUNK * 8 + 64];
     uint32_t ring_next[8];     // entropy wave -> output wave: Rice::next of the stream at the last barrier
     uint32_t ring_filled[8];   // entropy wave -> output wave at the start of a pass: bytes staged by rice_init
     uint32_t ring_on[8];       // stream switched on in this pass
@@ -982,13 +991,13 @@ __device__ uint32_t ab_entropy_pass(const alac_decode_params& p, AbShared& sh, c
         sh.ring_next[g] = rs.next;
     }
     for (int c = 0; c < nchunks; c++) {
-        const int i0 = c * CHUNK;
+        const int i0 = c * AB_CHUNK;
         int* q = (sub == 0) ? &sh.resq[c & 1][0][g] : &sh.dummy[lane];
         if (i0 < nmax) {
-            const bool fast_chunk = i0 + CHUNK <= nmin - 1;
+            const bool fast_chunk = i0 + AB_CHUNK <= nmin - 1;
             if (fast_chunk) {
 #pragma unroll
-                for (int u = 0; u < CHUNK; u += SPEC_UNIT) {
+                for (int u = 0; u < AB_CHUNK; u += SPEC_UNIT) {
                     const bool redo = !spec_unit<true, S, true>(rs, full_left, mc, mring, q + u * S);
                     if (redo) {
                         for (int ii = 0; ii < SPEC_UNIT; ii++)
@@ -997,7 +1006,7 @@ __device__ uint32_t ab_entropy_pass(const alac_decode_params& p, AbShared& sh, c
                 }
             } else {
                 const int qstride = (sub == 0) ? S : 0;
-                for (int ii = 0; ii < CHUNK; ii++) {
+                for (int ii = 0; ii < AB_CHUNK; ii++) {
                     const int i = i0 + ii;
                     int r = 0;
                     if (i < n_row) r = ab_zigzag(rice_step(rs, mc, n_row - 1 - i, i, &flags, mring));
@@ -1095,13 +1104,13 @@ __device__ void ab_fir_wave(const alac_decode_params& p, uint32_t pkt0, int lane
     const int nmin = __builtin_amdgcn_readfirstlane(-wave_max(stream_on ? -m.n : -0x7FFFFFFF));
     const int* qzero = &sh.zeros[0][g];
     for (int c = 0; c < nchunks; c++) {
-        const int i0 = c * CHUNK;
+        const int i0 = c * AB_CHUNK;
         const unsigned long long tb = p.dbg ? clock64() : 0;
         wg_sync();  // wait for chunk c
         if (p.dbg && lane == 0 && c > 0) p.dbg[8 * blockIdx.x + 7] += clock64() - tb;   // diagnostic: time spent in barriers
         const int* q = stream_on ? &sh.resq[c & 1][0][g] : qzero;
 #pragma unroll
-        for (int half = 0; half < 2; half++) {
+        for (int half = 0; half < AB_CHUNK / 8; half++) {
             const int ih = i0 + 8 * half;
             if (ih < nmax) {
                 if (ih > 8 && ih + 8 <= nmin) {
@@ -1120,7 +1129,7 @@ __device__ void ab_fir_wave(const alac_decode_params& p, uint32_t pkt0, int lane
                     }
                 }
             }
-            sh.outq[c & 1][half][0][lane] = f.hist;
+            sh.outq[c & 1][half][lane] = f.hist;
         }
     }
     wg_sync();  // final barrier of the pass
@@ -1138,7 +1147,9 @@ __device__ __forceinline__ int ab_finish24(const Meta& m, int val, int i, int ch
 
 // Ring refill service of the output wave (see AbShared): lane group r = lane >> 3 serves stream r, 16 bytes per lane.
 struct AbRefill {
-    static constexpr int ROUNDS = 2;           // up to 256 bytes per stream per chunk (a chunk consumes at most 118)
+    static constexpr int ROUNDS = 2;           // up to 256 bytes per stream per chunk (a chunk of 32 samples consumes at most 236)
+    // a sample costs at most 59 bits (a run-length symbol, 9 + 16, and an escaped value, 9 + 25): never fall behind
+    static_assert(AB_CHUNK * 59 <= ROUNDS * 128 * 8, "the ring refill must keep up with the worst-case consumption");
     const uint8_t* base;
     int64_t limit;
     AbShared& sh;
@@ -1210,11 +1221,11 @@ __device__ void ab_output_wave(const alac_decode_params& p, uint32_t pkt0, int l
         if (c < nch0) rf.issue(c == 0);
         if (c == 0) { rf.commit(); continue; }
 #pragma unroll
-        for (int half = 0; half < 2; half++) {
-            const int ih = (c - 1) * CHUNK + 8 * half;
+        for (int half = 0; half < AB_CHUNK / 8; half++) {
+            const int ih = (c - 1) * AB_CHUNK + 8 * half;
             const int cnt = min(8, n_out - ih);
             if (j >= cnt) continue;
-            const int mine = sh.outq[(c - 1) & 1][half][0][lane];   // lane (2t + par) holds out[last - t] of its stream
+            const int mine = sh.outq[(c - 1) & 1][half][lane];   // lane (2t + par) holds out[last - t] of its stream
             if (m.esc) {                                            // uncompressed: raw samples, both channels now
                 const int i = ih + j;
                 const int nch = m.stereo ? 2 : 1;
@@ -1239,25 +1250,27 @@ __device__ void ab_output_wave(const alac_decode_params& p, uint32_t pkt0, int l
     }
     if (nch1 == 0) return;
     // ---- pass 1: B arrives, A comes back from its parking place (loaded one chunk ahead) ----
-    int a_next[2] = {0, 0};
+    int a_next[AB_CHUNK / 8] = {};
     for (int c = 0; c <= nch1; c++) {
         wg_sync();
         if (c < nch1) rf.issue(c == 0);
-        int a_cur[2] = {a_next[0], a_next[1]};
+        int a_cur[AB_CHUNK / 8];
 #pragma unroll
-        for (int half = 0; half < 2; half++) {                      // A for chunk c (used after the next barrier)
-            const int ih = c * CHUNK + 8 * half;
+        for (int h = 0; h < AB_CHUNK / 8; h++) a_cur[h] = a_next[h];
+#pragma unroll
+        for (int half = 0; half < AB_CHUNK / 8; half++) {                      // A for chunk c (used after the next barrier)
+            const int ih = c * AB_CHUNK + 8 * half;
             const int cnt = min(8, n_out - ih);
             a_next[half] = (two_pass && c < nch1 && j < cnt) ? park[ih + cnt - 1 - j] : 0;
         }
         if (c == 0) { rf.commit(); continue; }
 #pragma unroll
-        for (int half = 0; half < 2; half++) {
-            const int ih = (c - 1) * CHUNK + 8 * half;
+        for (int half = 0; half < AB_CHUNK / 8; half++) {
+            const int ih = (c - 1) * AB_CHUNK + 8 * half;
             const int cnt = min(8, n_out - ih);
             if (!two_pass || j >= cnt) continue;
             const int i = ih + cnt - 1 - j;
-            const int a = a_cur[half], b = sh.outq[(c - 1) & 1][half][0][lane];
+            const int a = a_cur[half], b = sh.outq[(c - 1) & 1][half][lane];
             int left, right;
             if (m.mixweight != 0) {                                 // AlacFile.cs:346-357 / :377-388
                 right = wsub(a, wmul(b, m.mixweight) >> (m.mixshift & 31));
@@ -1296,9 +1309,9 @@ __device__ __forceinline__ void ab_kernel_body(const alac_decode_params& p) {
     const bool fallback = __builtin_amdgcn_ballot_w64(bad) != 0;
     if (p.ab_flags && threadIdx.x == 0) p.ab_flags[blockIdx.x] = fallback ? 1u : 0u;
     if (fallback) return;
-    const int nch0 = (__builtin_amdgcn_readfirstlane(wave_max(n0)) + CHUNK - 1) / CHUNK;
-    const int nch1 = (__builtin_amdgcn_readfirstlane(wave_max(n1)) + CHUNK - 1) / CHUNK;
-    for (int t = threadIdx.x; t < CHUNK * 8; t += blockDim.x) (&sh.zeros[0][0])[t] = 0;
+    const int nch0 = (__builtin_amdgcn_readfirstlane(wave_max(n0)) + AB_CHUNK - 1) / AB_CHUNK;
+    const int nch1 = (__builtin_amdgcn_readfirstlane(wave_max(n1)) + AB_CHUNK - 1) / AB_CHUNK;
+    for (int t = threadIdx.x; t < AB_CHUNK * 8; t += blockDim.x) (&sh.zeros[0][0])[t] = 0;
     if (p.dbg && lane == 0) {   // diagnostic (ALACGPU_DEBUG_STAMPS): where each wave runs, when the workgroup starts
         const unsigned hw = __builtin_amdgcn_s_getreg(63492), xcc = __builtin_amdgcn_s_getreg(63508);
         if (wave == 0) {
