@@ -82,7 +82,9 @@ int alacgpu_cfg_from_codec_data(const int32_t* codec_data_ints, uint32_t n_ints,
  *   pcm_out              packet p decodes to pcm_out + p*slot_ints, ONE int32 PER SAMPLE interleaved by the
  *                        stream's num_channels (16-bit: exactly the ints DecodeFrame stores; 24-bit: the
  *                        sample sign-extended -- DecodeFrame's byte-per-int layout is alacgpu_expand_reference_layout)
- *   slot_ints            >= max n*num_channels over the batch
+ *   slot_ints            >= max n*num_channels over the batch.  What a slot holds beyond the packet's own output
+ *                        (n*num_channels ints, or out_bytes[p] bytes in the packed format) is unspecified: the kernels
+ *                        use the slot as scratch while they decode
  *   out_bytes[p]         DecodeFrame's return value (AlacFile.cs:718); may be NULL
  *   out_samples[p]       samples per channel in packet p; may be NULL
  *   status[p]            ALACGPU_ST_*
