@@ -948,7 +948,7 @@ struct AbShared {
 // and converts it, fir8_step<.., true>): the inverse of r = (dv >> 1) ^ -(dv & 1) for what rice_step hands back.
 __device__ __forceinline__ int ab_zigzag(int r) { return (int)(((uint32_t)r << 1) ^ (uint32_t)(r >> 31)); }
 
-__device__ uint32_t ab_entropy_pass(const alac_decode_params& p, AbShared& sh, const Meta& m, const RiceCfg& rc, int init_hist,
+__device__ __forceinline__ uint32_t ab_entropy_pass(const alac_decode_params& p, AbShared& sh, const Meta& m, const RiceCfg& rc, int init_hist,
                                     uint32_t startbit, bool stream_on, int g, int sub, int lane, int nchunks, int* flags_out) {
     constexpr int S = 8, LPS = 8;
     const int n_row = stream_on ? m.n : 0;
@@ -1024,7 +1024,7 @@ __device__ uint32_t ab_entropy_pass(const alac_decode_params& p, AbShared& sh, c
     return rice_bitpos(rs);
 }
 
-__device__ void ab_entropy_wave(const alac_decode_params& p, uint32_t pkt0, int lane, AbShared& sh, int nch0, int nch1) {
+__device__ __forceinline__ void ab_entropy_wave(const alac_decode_params& p, uint32_t pkt0, int lane, AbShared& sh, int nch0, int nch1) {
     const int g = lane >> 3, sub = lane & 7;
     const uint32_t pkt = pkt0 + (uint32_t)g;
     const bool valid = pkt < p.n_packets;
@@ -1043,12 +1043,15 @@ __device__ void ab_entropy_wave(const alac_decode_params& p, uint32_t pkt0, int 
     rc.rss = m.rss;
     int flags_a = 0, flags_b = 0;
     uint32_t end_a = m.ricebit, end_b = m.ricebit;
-    end_a = ab_entropy_pass(p, sh, m, rc, cfg.rice_initial_history, m.ricebit, compressed, g, sub, lane, nch0, &flags_a);
-    end_b = end_a;
-    if (p.dbg && lane == 0) p.dbg[8 * blockIdx.x + 1] = clock64();
-    if (nch1 > 0) {
-        rc.hist_mult = mb.ricemod * (cfg.rice_history_mult / 4);
-        end_b = ab_entropy_pass(p, sh, m, rc, cfg.rice_initial_history, end_a, compressed && m.stereo, g, sub, lane, nch1, &flags_b);
+    // one copy of the pass's code for both channels (two would not fit the instruction cache next to the other waves' code)
+    for (int ph = 0; ph < (nch1 > 0 ? 2 : 1); ph++) {
+        int fl = 0;
+        rc.hist_mult = (ph ? mb.ricemod : m.ricemod) * (cfg.rice_history_mult / 4);
+        const uint32_t end = ab_entropy_pass(p, sh, m, rc, cfg.rice_initial_history, ph ? end_a : m.ricebit,
+                                             compressed && (ph == 0 || m.stereo), g, sub, lane, ph ? nch1 : nch0, &fl);
+        if (ph == 0) { end_a = end_b = end; flags_a = fl; }
+        else { end_b = end; flags_b = fl; }
+        if (p.dbg && lane == 0 && ph == 0) p.dbg[8 * blockIdx.x + 1] = clock64();
     }
     // ---- status, in the reference's control-flow order (same as the other kernels / the oracle) ----
     if (valid && sub == 0) {
@@ -1075,7 +1078,7 @@ __device__ void ab_entropy_wave(const alac_decode_params& p, uint32_t pkt0, int 
 }
 
 // FIR wave: the P8 layout of recon8_wave with the 8 rows' two parities holding the SAME channel of 8 different packets.
-__device__ void ab_fir_wave(const alac_decode_params& p, uint32_t pkt0, int lane, AbShared& sh, int ph, int nchunks) {
+__device__ __forceinline__ void ab_fir_wave(const alac_decode_params& p, uint32_t pkt0, int lane, AbShared& sh, int ph, int nchunks) {
     constexpr int S = 8;
     const int row = lane >> 4, l = lane & 15, par = l & 1, j = l >> 1;
     const int g = 2 * row + par;
@@ -1203,7 +1206,7 @@ struct AbRefill {
     }
 };
 
-__device__ void ab_output_wave(const alac_decode_params& p, uint32_t pkt0, int lane, AbShared& sh, int nch0, int nch1) {
+__device__ __forceinline__ void ab_output_wave(const alac_decode_params& p, uint32_t pkt0, int lane, AbShared& sh, int nch0, int nch1) {
     const int row = lane >> 4, l = lane & 15, par = l & 1, j = l >> 1;
     const int g = 2 * row + par;
     const uint32_t pkt = pkt0 + (uint32_t)g;
@@ -1327,8 +1330,7 @@ __device__ __forceinline__ void ab_kernel_body(const alac_decode_params& p) {
     } else if (wave == 1) {
         ab_output_wave(p, pkt0, lane, sh, nch0, nch1);
     } else {
-        ab_fir_wave(p, pkt0, lane, sh, 0, nch0);
-        if (nch1 > 0) ab_fir_wave(p, pkt0, lane, sh, 1, nch1);
+        for (int ph = 0; ph < (nch1 > 0 ? 2 : 1); ph++) ab_fir_wave(p, pkt0, lane, sh, ph, ph ? nch1 : nch0);
     }
 }
 
