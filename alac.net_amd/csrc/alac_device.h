@@ -246,6 +246,42 @@ __device__ __forceinline__ int rice_spec_step(Rice& s, const RiceCfg& c, uint32_
     s.hist = hn;
     return r;
 }
+// rice_spec_step plus escape codes (nine 1s + rss raw bits, AlacFile.cs:198-202), for rss <= 23: the raw value then lies
+// inside the 32-bit window (9 + rss <= 32), and a step still consumes at most 32 bits -- the window slides by at most one
+// dword, so this is the plain step plus four instructions (the escape-capable rice_spec_step_full costs twenty more).
+// Loud / noisy 16-bit content lives here.
+template <bool WANT_R, bool RAW = false>
+__device__ __forceinline__ int rice_spec_step_esc(Rice& s, const RiceCfg& c, uint32_t ring, uint32_t& xmax,
+                                                  int& hmin) {
+    const uint32_t win = rice_window(s);
+    const uint32_t x = (uint32_t)__builtin_clz(~win | 0x00400000u);
+    const bool esc = x > 8u;
+    xmax = max(xmax, x);
+    const int k = min(22 - __builtin_clz((uint32_t)(s.hist + 1536)), c.kmod);
+    const uint32_t e = __builtin_amdgcn_ubfe(win, (uint32_t)(31 - k) - x, (uint32_t)k);
+    const uint32_t m = __builtin_amdgcn_ubfe(0xFFFFFFFFu, 0u, (uint32_t)k);
+    const uint32_t vn = __umul24(x, m) + (e > 1u ? e - 1u : 0u);
+    const uint32_t raw = __builtin_amdgcn_ubfe(win, (uint32_t)(23 - c.rss), (uint32_t)c.rss);   // bits 9 .. 9+rss of the window
+    const uint32_t v = esc ? raw : vn;
+    const uint32_t used = esc ? (uint32_t)(9 + c.rss) : x + (uint32_t)k + (e > 1u ? 1u : 0u);
+    const uint32_t cur2 = s.cur - used;
+    int r = 0;
+    if (WANT_R) r = RAW ? (int)v : (int)(v >> 1) ^ -(int)(v & 1u);
+    const int h = s.hist;
+    int hx = (int)(__umul24(v, (uint32_t)c.hist_mult) + (uint32_t)h) - (wmul(h, c.hist_mult) >> 9);
+    asm volatile("" : "+v"(hx));
+    const int hn = (int)v > 0xFFFF ? 0xFFFF : hx;
+    hmin = min(hmin, hn);
+    const uint32_t a2 = rice_w2_addr(cur2, ring);
+    const bool adv = a2 != s.ra;
+    s.cur = cur2;
+    s.w0 = adv ? s.w1 : s.w0;
+    s.w1 = adv ? s.w2 : s.w1;
+    s.ra = a2;
+    s.w2 = lds_load(a2);
+    s.hist = hn;
+    return r;
+}
 // Same, for units in which some lane starts inside a zero run or with signModifier pending (digital
 // silence): such a lane emits 0 without touching the bitstream while zrun > 0, and adds signModifier to
 // its next value.  Still straight-line; only a NEW run symbol (history < 128 after a value) or an escape

@@ -277,20 +277,49 @@ __device__ __forceinline__ T wave_max(T v) {
 // One speculative unit (SPEC_UNIT samples) of the entropy wave.  Tiers, cheapest first:
 //   1  rice_spec_step       plain values only
 //   2  rice_spec_step_z     + zero runs in progress / signModifier pending   (digital silence)
-//   3  rice_spec_step_full  + escape codes                                   (loud / noisy content)
+//   1E rice_spec_step_esc   plain values and escape codes, raw value <= 23 bits (loud / noisy 16-bit content)
+//   3  rice_spec_step_full  + escape codes of any width, together with zero runs / signModifier
 // A unit whose lanes met something its tier cannot do is restored from its snapshot and retried higher; a NEW run
 // symbol (history < 128 after a value) is beyond all tiers: the function then returns false with the state
-// restored, and the caller decodes the unit with rice_step.  After an escape was seen the wave stays on tier 3 for
-// FULL_HOLD clean units (escapes come in stretches, and a failed cheaper attempt costs a whole unit).
+// restored, and the caller decodes the unit with rice_step.  After an escape was seen the wave stays on the escape
+// tier for ESC_HOLD / FULL_HOLD clean units (a failed cheaper attempt costs a whole unit; measured on cfg2:
+// hold 0 / 1 / 2 / 4 / 8 -> 0.828 / 0.815 / 0.825 / 0.843 / 0.858 ms).
 #ifndef ALAC_FULL_HOLD
 #define ALAC_FULL_HOLD 1
 #endif
 constexpr int FULL_HOLD = ALAC_FULL_HOLD;
 
+#ifndef ALAC_ESC_HOLD
+#define ALAC_ESC_HOLD 1
+#endif
+constexpr int ESC_HOLD = ALAC_ESC_HOLD;
+
+// After a tier-1-like pass: the parked lanes (see spec_unit) drop out of the verdict and get their state back.
+template <bool WANT_R, int QSTRIDE>
+__device__ __forceinline__ void spec_unpark(Rice& rs, const Rice& snap, bool parked, uint32_t& xmax, int& hmin, int* q) {
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(parked) != 0, 0)) {
+        xmax = parked ? 0u : xmax;
+        hmin = parked ? 0x7FFFFFFF : hmin;
+        if (parked) {
+            rs.w0 = snap.w0; rs.w1 = snap.w1; rs.w2 = snap.w2;
+            rs.cur = snap.cur; rs.ra = snap.ra; rs.hist = snap.hist;
+            rs.zrun = snap.zrun - SPEC_UNIT;
+            if (WANT_R) {
+#pragma unroll
+                for (int ii = 0; ii < SPEC_UNIT; ii++) q[ii * QSTRIDE] = 0;
+            }
+        }
+    }
+}
+
 template <bool WANT_R, int QSTRIDE, bool RAW = false>
 __device__ __forceinline__ bool spec_unit(Rice& rs, int& full_left, const RiceCfg& c, uint32_t ring, int* q) {
     const Rice snap = rs;
-    const bool special = __builtin_amdgcn_ballot_w64(rs.nforce == 0u) != 0;
+    // A stream whose zero run covers the whole unit is PARKED: its lanes run the plain code with everybody else (on
+    // whatever their window shows -- harmless, see rice_spec_step), are left out of the unit's verdict and get their state
+    // back afterwards, minus SPEC_UNIT zeros: one silent stream does not keep the other seven on tier 2.
+    const bool parked = rs.zrun >= SPEC_UNIT;
+    const bool special = __builtin_amdgcn_ballot_w64(rs.nforce == 0u && !parked) != 0;
     uint32_t xmax = 0;
     int hmin = 0x7FFFFFFF;
     if (full_left == 0) {
@@ -300,6 +329,7 @@ __device__ __forceinline__ bool spec_unit(Rice& rs, int& full_left, const RiceCf
                 const int r = rice_spec_step<WANT_R, RAW>(rs, c, ring, xmax, hmin);
                 if (WANT_R) q[ii * QSTRIDE] = r;
             }
+            spec_unpark<WANT_R, QSTRIDE>(rs, snap, parked, xmax, hmin, q);
         } else {
 #pragma unroll
             for (int ii = 0; ii < SPEC_UNIT; ii++) {
@@ -313,19 +343,30 @@ __device__ __forceinline__ bool spec_unit(Rice& rs, int& full_left, const RiceCf
         if (__builtin_expect(!newrun && !sawesc, 1)) return true;
         rs = snap;
         if (newrun) return false;          // no tier can do it
-        full_left = FULL_HOLD;             // escapes: go on with tier 3
+        full_left = 1;                     // escapes: go on with an escape-capable tier
         xmax = 0;
         hmin = 0x7FFFFFFF;
     }
-    uint32_t w3 = lds_load(((rs.ra + 4u) & RING_MASK) | ring);
+    if (!special && __builtin_amdgcn_ballot_w64(c.rss > 23) == 0) {   // tier 1E (rss is per stream: ask the whole wave)
 #pragma unroll
-    for (int ii = 0; ii < SPEC_UNIT; ii++) {
-        const int r = rice_spec_step_full<WANT_R, RAW>(rs, w3, c, ring, xmax, hmin);
-        if (WANT_R) q[ii * QSTRIDE] = r;
+        for (int ii = 0; ii < SPEC_UNIT; ii++) {
+            const int r = rice_spec_step_esc<WANT_R, RAW>(rs, c, ring, xmax, hmin);
+            if (WANT_R) q[ii * QSTRIDE] = r;
+        }
+        spec_unpark<WANT_R, QSTRIDE>(rs, snap, parked, xmax, hmin, q);
+        const bool sawesc = __builtin_amdgcn_ballot_w64(xmax > 8u) != 0;
+        full_left = sawesc ? ESC_HOLD : full_left - 1;
+    } else {                               // tier 3
+        uint32_t w3 = lds_load(((rs.ra + 4u) & RING_MASK) | ring);
+#pragma unroll
+        for (int ii = 0; ii < SPEC_UNIT; ii++) {
+            const int r = rice_spec_step_full<WANT_R, RAW>(rs, w3, c, ring, xmax, hmin);
+            if (WANT_R) q[ii * QSTRIDE] = r;
+        }
+        rs.nforce = (rs.zrun > 0 || rs.signmod != 0) ? 0u : 0xFFFFFFFFu;
+        const bool sawesc = __builtin_amdgcn_ballot_w64(xmax > 8u) != 0;
+        full_left = sawesc ? FULL_HOLD : full_left - 1;
     }
-    rs.nforce = (rs.zrun > 0 || rs.signmod != 0) ? 0u : 0xFFFFFFFFu;
-    const bool sawesc = __builtin_amdgcn_ballot_w64(xmax > 8u) != 0;
-    full_left = sawesc ? FULL_HOLD : full_left - 1;
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(hmin < 128) != 0, 0)) {
         rs = snap;
         return false;
