@@ -364,6 +364,46 @@ __device__ __forceinline__ int rice_spec_step_full(Rice& s, uint32_t& w3, const 
     s.zrun -= inrun ? 1 : 0;
     return r;
 }
+// rice_spec_step_esc for any rss (24-bit streams: the raw value of an escape is up to 25 bits and reaches into the next
+// window; a step consumes up to 34 bits, so the window slides by 0, 1 or 2 dwords and w3 is kept prefetched, as in
+// rice_spec_step_full) -- but without that step's zero-run / signModifier selects.
+template <bool WANT_R, bool RAW = false>
+__device__ __forceinline__ int rice_spec_step_esc_wide(Rice& s, uint32_t& w3, const RiceCfg& c, uint32_t ring, uint32_t& xmax,
+                                                       int& hmin) {
+    const uint32_t win = rice_window(s);
+    const uint32_t win2 = __builtin_amdgcn_alignbit(s.w1, s.w2, s.cur);
+    const uint32_t x = (uint32_t)__builtin_clz(~win | 0x00400000u);
+    const bool esc = x > 8u;
+    xmax = max(xmax, x);
+    const int k = min(22 - __builtin_clz((uint32_t)(s.hist + 1536)), c.kmod);
+    const uint32_t e = __builtin_amdgcn_ubfe(win, (uint32_t)(31 - k) - x, (uint32_t)k);
+    const uint32_t m = __builtin_amdgcn_ubfe(0xFFFFFFFFu, 0u, (uint32_t)k);
+    const uint32_t vn = __umul24(x, m) + (e > 1u ? e - 1u : 0u);
+    const uint32_t raw = __builtin_amdgcn_alignbit(win, win2, 23) >> (32 - c.rss);
+    const uint32_t v = esc ? raw : vn;
+    const uint32_t used = esc ? (uint32_t)(9 + c.rss) : x + (uint32_t)k + (e > 1u ? 1u : 0u);
+    const uint32_t cur2 = s.cur - used;
+    int r = 0;
+    if (WANT_R) r = RAW ? (int)v : (int)(v >> 1) ^ -(int)(v & 1u);
+    const int h = s.hist;
+    int hx = (int)(__umul24(v, (uint32_t)c.hist_mult) + (uint32_t)h) - (wmul(h, c.hist_mult) >> 9);
+    asm volatile("" : "+v"(hx));
+    const int hn = (int)v > 0xFFFF ? 0xFFFF : hx;
+    hmin = min(hmin, hn);
+    const uint32_t na = rice_w2_addr(cur2, ring);
+    const bool a1 = na != s.ra;
+    const bool a2 = na == (((s.ra + 8u) & RING_MASK) | ring);
+    s.cur = cur2;
+    const uint32_t n0 = a2 ? s.w2 : (a1 ? s.w1 : s.w0);
+    const uint32_t n1 = a2 ? w3 : (a1 ? s.w2 : s.w1);
+    s.w0 = n0;
+    s.w1 = n1;
+    s.ra = na;
+    s.w2 = lds_load(na);
+    w3 = lds_load(((na + 4u) & RING_MASK) | ring);
+    s.hist = hn;
+    return r;
+}
 constexpr int SPEC_UNIT = 8;   // steps per speculative unit
 
 // ---- per-row LDS ring ------------------------------------------------------------------------------

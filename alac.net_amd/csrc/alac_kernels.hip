@@ -278,7 +278,8 @@ __device__ __forceinline__ T wave_max(T v) {
 //   1  rice_spec_step       plain values only
 //   2  rice_spec_step_z     + zero runs in progress / signModifier pending   (digital silence)
 //   1E rice_spec_step_esc   plain values and escape codes, raw value <= 23 bits (loud / noisy 16-bit content)
-//   3  rice_spec_step_full  + escape codes of any width, together with zero runs / signModifier
+//      rice_spec_step_esc_wide  the same for wider raw values (24-bit streams; the window slides by up to two dwords)
+//   3  rice_spec_step_full  escape codes of any width together with zero runs / signModifier
 // A unit whose lanes met something its tier cannot do is restored from its snapshot and retried higher; a NEW run
 // symbol (history < 128 after a value) is beyond all tiers: the function then returns false with the state
 // restored, and the caller decodes the unit with rice_step.  After an escape was seen the wave stays on the escape
@@ -351,6 +352,16 @@ __device__ __forceinline__ bool spec_unit(Rice& rs, int& full_left, const RiceCf
 #pragma unroll
         for (int ii = 0; ii < SPEC_UNIT; ii++) {
             const int r = rice_spec_step_esc<WANT_R, RAW>(rs, c, ring, xmax, hmin);
+            if (WANT_R) q[ii * QSTRIDE] = r;
+        }
+        spec_unpark<WANT_R, QSTRIDE>(rs, snap, parked, xmax, hmin, q);
+        const bool sawesc = __builtin_amdgcn_ballot_w64(xmax > 8u) != 0;
+        full_left = sawesc ? ESC_HOLD : full_left - 1;
+    } else if (!special) {                 // tier 1E for wide raw values (24-bit streams)
+        uint32_t w3 = lds_load(((rs.ra + 4u) & RING_MASK) | ring);
+#pragma unroll
+        for (int ii = 0; ii < SPEC_UNIT; ii++) {
+            const int r = rice_spec_step_esc_wide<WANT_R, RAW>(rs, w3, c, ring, xmax, hmin);
             if (WANT_R) q[ii * QSTRIDE] = r;
         }
         spec_unpark<WANT_R, QSTRIDE>(rs, snap, parked, xmax, hmin, q);
