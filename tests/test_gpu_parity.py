@@ -473,3 +473,47 @@ def test_tiny_batches_and_degenerate_packets(pkg, oracle, synth, variant):
     g, o = run_both(pkg, oracle, b, variant=variant)
     assert o[3].tolist()[-1] == 0 and all(s != 0 for s in o[3].tolist()[:-1])
     assert_same(g, o, b["stream_cfgs"], None)
+
+
+@pytest.mark.parametrize("variant", [3, 4, 5])
+@pytest.mark.parametrize("is24", [False, True])
+@pytest.mark.parametrize("content", ["loud", "one_silent_stream_in_eight", "very_quiet"])
+def test_speculative_tiers_on_full_length_streams(pkg, oracle, synth, variant, is24, content):
+    # Full-length packets of equal length keep the entropy wave on its speculative units from the first chunk to the
+    # last, so the tier a unit lands on is decided by the content alone:
+    #   loud                         escape codes in most units (rice_spec_step_esc; _esc_wide for 24-bit raw values)
+    #   one_silent_stream_in_eight   long zero runs in one stream of a wave while the others carry signal (parked streams)
+    #   very_quiet                   new run symbols every few samples (units redone by rice_step, run-aware tier)
+    count = 32
+    rng = np.random.default_rng(5150 + is24)
+    d = synth.packet_descs(count, max_samples_per_frame=4096, sample_size=24 if is24 else 16, stereo=1)
+    d["n"] = np.full(count, 4096)
+    d["pred_order"] = rng.integers(1, 9, (count, 2))
+    d["ub"] = rng.integers(0, 3 if is24 else 1, count)
+    d["mix_shift"] = rng.integers(0, 4, count)
+    d["mix_weight"] = np.minimum(rng.integers(0, 8, count), 1 << d["mix_shift"].astype(np.int64))
+    sig = synth.default_signal(31337)
+    sig["silence_prob"] = 0.0
+    if content == "loud":
+        sig["amp_lo_log2"], sig["amp_hi_log2"], sig["noise_sigma"] = 14.0, 15.0, 12000.0
+        b = synth.make_batch(d, sig, want_pcm=True)
+    elif content == "very_quiet":
+        sig["amp_lo_log2"], sig["amp_hi_log2"], sig["noise_sigma"] = 2.0, 5.0, 2.0
+        b = synth.make_batch(d, sig, want_pcm=True)
+    else:
+        silent = synth.default_signal(31337)
+        silent["silence_prob"], silent["silence_min"], silent["silence_max"] = 1.0, 3000, 4000
+        parts = []
+        for p in range(count):     # packet 8k+3 is the silent one of its workgroup
+            parts.append(synth.make_batch(d[p:p + 1], silent if p % 8 == 3 else sig, first_index=p, want_pcm=True))
+        blob = np.concatenate([x["blob"][int(x["offsets"][0]):int(x["offsets"][0]) + int(x["sizes"][0])] for x in parts] +
+                              [np.zeros(16, dtype=np.uint8)])     # slack after the last packet, as make_batch leaves
+        sizes = np.array([int(x["sizes"][0]) for x in parts], dtype=np.uint32)
+        offsets = np.concatenate([[0], np.cumsum(sizes[:-1], dtype=np.uint64)]).astype(np.uint64)
+        b = dict(blob=blob, offsets=offsets, sizes=sizes, slot_ints=parts[0]["slot_ints"],
+                 pcm=np.concatenate([x["pcm"] for x in parts]))
+    b.update(stream_cfgs=[(4096, 24 if is24 else 16, 40, 10, 14, 2)], cfg_idx=None)
+    g, o = run_both(pkg, oracle, b, variant=variant)
+    assert (o[3] == 0).all()
+    assert_same(g, o, b["stream_cfgs"], None)
+    assert np.array_equal(g[0][:, :8192], b["pcm"][:, :8192])

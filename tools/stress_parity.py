@@ -39,6 +39,7 @@ def main():
     rng = np.random.default_rng(seed)
     t0 = time.time()
     rounds = packets = skipped = 0
+    last_note = t0
     while time.time() - t0 < budget:
         stereo, is24 = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
         orders = [np.arange(0, 32), np.arange(1, 9), np.array([8]), np.arange(9, 17), np.arange(17, 32)][int(rng.integers(0, 5))]
@@ -72,6 +73,9 @@ def main():
                                          f"n {d['n'][p]} first bad index {bad[:5]}")
         rounds += 1
         packets += count
+        if time.time() - last_note > 30:    # a long run has to show signs of life (gpurun kills silent commands)
+            last_note = time.time()
+            print(f"... {rounds} rounds, {packets} packets, {time.time() - t0:.0f} s", flush=True)
     print(f"stress ok: {rounds} rounds, {packets} packets x 5 kernel variants, {time.time() - t0:.0f} s, seed {seed}, {skipped} recipes skipped")
 
 
