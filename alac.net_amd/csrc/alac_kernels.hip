@@ -1190,6 +1190,70 @@ __device__ __forceinline__ void ab_fir_wave(const alac_decode_params& p, uint32_
     wg_sync();  // final barrier of the pass
 }
 
+// The same wave for workgroups in which some stream has 9 <= N <= 16: two taps per lane (fir8x2_step).
+__device__ __forceinline__ void ab_fir_wave2(const alac_decode_params& p, uint32_t pkt0, int lane, AbShared& sh, int ph, int nchunks) {
+    constexpr int S = 8;
+    const int row = lane >> 4, l = lane & 15, par = l & 1, j = l >> 1;
+    const int g = 2 * row + par;
+    const uint32_t pkt = pkt0 + (uint32_t)g;
+    const bool valid = pkt < p.n_packets;
+    alacgpu_cfg_dev cfg;
+    const Meta m = parse_meta(p, pkt, ph, valid, cfg);
+    const bool stream_on = valid && m.status == 0 && !m.esc && (ph == 0 || m.stereo);
+    const int n_row = stream_on ? m.n : 0;
+    Fir8Lane2 f;
+    f.base = 0;
+    f.prev = 0;
+    f.q = stream_on ? m.q : 1;
+    f.rnd = stream_on ? m.rnd : 0;
+    f.rss = stream_on ? m.rss : 16;
+    f.qmask = (1 << f.q) - 1;
+    f.N = stream_on ? m.N : 0;
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int tapno = j + 8 * t;
+        const bool tap = stream_on && tapno < m.N;
+        f.hist[t] = 0;
+        f.coef[t] = tap ? (int)(int16_t)peek_bits(m.base, m.limit, m.coefbit + 16u * tapno, 16) : 0;
+        f.tlo[t] = tap ? -1 : 0;
+        f.thi[t] = tap ? 1 : 0;
+        f.w[t] = tap ? (uint32_t)(m.N - tapno) : 0u;
+    }
+    f.bpaddr = ((lane & 48) + 2 * (stream_on ? (m.N - 1) & 7 : 0) + par) * 4;
+    f.bphi = stream_on && m.N > 8;
+    const int nmax = __builtin_amdgcn_readfirstlane(wave_max(n_row));
+    const int nmin = __builtin_amdgcn_readfirstlane(-wave_max(stream_on ? -m.n : -0x7FFFFFFF));
+    const int* qzero = &sh.zeros[0][g];
+    for (int c = 0; c < nchunks; c++) {
+        const int i0 = c * AB_CHUNK;
+        wg_sync();  // wait for chunk c
+        const int* q = stream_on ? &sh.resq[c & 1][0][g] : qzero;
+#pragma unroll
+        for (int half = 0; half < AB_CHUNK / 8; half++) {
+            const int ih = i0 + 8 * half;
+            if (ih < nmax) {
+                if (ih > 16 && ih + 8 <= nmin) {
+                    int err = q[(8 * half) * S];
+#pragma unroll
+                    for (int ii = 0; ii < 8; ii++) {
+                        const int en = q[(8 * half + (ii < 7 ? ii + 1 : ii)) * S];
+                        fir8x2_step<false, true>(f, err, ih + ii, true);
+                        err = en;
+                    }
+                } else {
+                    for (int ii = 0; ii < 8; ii++) {
+                        const int i = ih + ii;
+                        const int err = q[(8 * half + ii) * S];
+                        fir8x2_step<true, true>(f, err, i, i < n_row);
+                    }
+                }
+            }
+            sh.outq[c & 1][half][lane] = f.hist[0];
+        }
+    }
+    wg_sync();  // final barrier of the pass
+}
+
 // 24-bit streams: merge the sample's shift bytes (AlacFile.cs:390-395) and sign-extend to 24 bits (:555-557).
 __device__ __forceinline__ int ab_finish24(const Meta& m, int val, int i, int chan) {
     if (m.ss != 24) return val;
@@ -1347,7 +1411,7 @@ __device__ __forceinline__ void ab_kernel_body(const alac_decode_params& p) {
     const uint32_t pkt0 = blockIdx.x * (uint32_t)AB_PPW;
     // every wave reads all 8 headers: pass lengths (uniform over the workgroup) and whether the P8 layout fits
     int n0 = 0, n1 = 0;
-    bool bad = false;
+    bool bad = false, wide_lane = false;
     {
         const uint32_t pk = pkt0 + (uint32_t)(lane & 7);
         const bool v = pk < p.n_packets;
@@ -1357,11 +1421,13 @@ __device__ __forceinline__ void ab_kernel_body(const alac_decode_params& p) {
         const bool ok = v && ma.status == 0;
         n0 = ok ? ma.n : 0;
         n1 = (ok && !ma.esc && ma.stereo) ? ma.n : 0;
-        bad = ok && !ma.esc && (ma.N < 1 || ma.N > 8 || (ma.stereo && (mb.N < 1 || mb.N > 8)));
+        bad = ok && !ma.esc && (ma.N < 1 || ma.N > 16 || (ma.stereo && (mb.N < 1 || mb.N > 16)));
+        wide_lane = ok && !ma.esc && (ma.N > 8 || (ma.stereo && mb.N > 8));
         // the parking place needs two ints per sample in the slot (always true for a two-channel stream cfg)
         bad = bad || (n1 > 0 && (uint64_t)2 * (uint64_t)ma.n > p.slot_ints);
     }
     const bool fallback = __builtin_amdgcn_ballot_w64(bad) != 0;
+    const bool wide = __builtin_amdgcn_ballot_w64(wide_lane) != 0;   // some stream has more than 8 taps: two taps per lane
     if (p.ab_flags && threadIdx.x == 0) p.ab_flags[blockIdx.x] = fallback ? 1u : 0u;
     if (fallback) return;
     const int nch0 = (__builtin_amdgcn_readfirstlane(wave_max(n0)) + AB_CHUNK - 1) / AB_CHUNK;
@@ -1382,7 +1448,11 @@ __device__ __forceinline__ void ab_kernel_body(const alac_decode_params& p) {
     } else if (wave == 1) {
         ab_output_wave(p, pkt0, lane, sh, nch0, nch1);
     } else {
-        for (int ph = 0; ph < (nch1 > 0 ? 2 : 1); ph++) ab_fir_wave(p, pkt0, lane, sh, ph, ph ? nch1 : nch0);
+        if (__builtin_expect(!wide, 1)) {
+            for (int ph = 0; ph < (nch1 > 0 ? 2 : 1); ph++) ab_fir_wave(p, pkt0, lane, sh, ph, ph ? nch1 : nch0);
+        } else {
+            for (int ph = 0; ph < (nch1 > 0 ? 2 : 1); ph++) ab_fir_wave2(p, pkt0, lane, sh, ph, ph ? nch1 : nch0);
+        }
     }
 }
 
