@@ -404,7 +404,10 @@ __device__ __forceinline__ int rice_spec_step_esc_wide(Rice& s, uint32_t& w3, co
     s.hist = hn;
     return r;
 }
-constexpr int SPEC_UNIT = 8;   // steps per speculative unit
+#ifndef ALAC_SPEC_UNIT
+#define ALAC_SPEC_UNIT 8
+#endif
+constexpr int SPEC_UNIT = ALAC_SPEC_UNIT;   // steps per speculative unit
 
 // ---- per-row LDS ring ------------------------------------------------------------------------------
 // Tops the ring up with 256-byte chunks while there is room in front of the oldest live dword.

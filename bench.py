@@ -192,8 +192,8 @@ def main():
                        4: "alac_decode_split4_kernel", 5: "alac_decode_ab_kernel"}[args.variant or auto]
         if all_mono and (args.variant or auto) in (3, 4):
             kernel_name = kernel_name.replace("_kernel", "_mono_kernel")
-        if (args.variant or auto) == 5 and args.config in (3, 5):
-            # LPC orders above 8: the two-pass kernel hands (nearly) every workgroup to the split kernel launched behind it
+        if (args.variant or auto) == 5 and args.config == 5:
+            # LPC orders above 16: the two-pass kernel hands (nearly) every workgroup to the split kernel launched behind it
             kernel_name = "alac_decode_split%d_kernel (behind alac_decode_ab_kernel)" % (4 if split_auto == 4 else 2)
         # HBM traffic comes from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read in-process):
         # the committed measurement of the same workload + kernel, see profiles/
