@@ -39,9 +39,10 @@ struct alac_decode_params {
     int32_t* status;
     uint32_t out_format;        // 0: one int32 per sample; 1: packed little-endian PCM bytes (FormatSamples fused)
     unsigned long long* dbg;    // diagnostic builds only: per-workgroup s_memtime stamps (null in normal use)
-    // Two-pass kernel (alac_decode_ab_kernel) and its fallback: flag g covers packets 8g .. 8g+7.  The two-pass
-    // kernel writes 1 where it left the group to the fallback launch, 0 where it decoded it; the split kernels, when
-    // handed the array, decode only the groups flagged 1.  Null: no such protocol (a kernel does every packet).
+    // Two-pass kernels (alac_decode_ab_kernel, then alac_decode_ab32_kernel) and their fallback: flag g covers packets
+    // 8g .. 8g+7.  The first writes 0 where it decoded the group and 1 where it did not; the second looks at the groups
+    // flagged 1 and writes 2 where it decoded one; the split kernels, when handed the array, decode only the groups
+    // still flagged 1.  Null: no such protocol (a kernel does every packet).
     uint32_t* ab_flags;
 };
 
@@ -50,6 +51,7 @@ extern "C" __global__ void alac_decode_packets_kernel(alac_decode_params p);   /
 extern "C" __global__ void alac_decode_split1_kernel(alac_decode_params p);    // v2: 1 entropy + 1 recon wave, 2 packets
 extern "C" __global__ void alac_decode_split2_kernel(alac_decode_params p);    // v2: 1 entropy + 2 recon waves, 4 packets
 extern "C" __global__ void alac_decode_ab_kernel(alac_decode_params p);        // v3: two passes (channel A, then B), 8 stereo packets / 192-thread WG
+extern "C" __global__ void alac_decode_ab32_kernel(alac_decode_params p);      // v3 for LPC orders 17..31: two FIR waves (16-lane layout, 2 tap registers) / 256-thread WG
 extern "C" __global__ void alac_decode_split4_kernel(alac_decode_params p);    // v2: 1 entropy + 4 recon waves, 8 packets
 extern "C" __global__ void alac_decode_split2_mono_kernel(alac_decode_params p);  // one-channel streams: 8 packets / WG
 extern "C" __global__ void alac_decode_split4_mono_kernel(alac_decode_params p);  // one-channel streams: 16 packets / WG

@@ -934,7 +934,7 @@ __device__ __forceinline__ void split_kernel_body(const alac_decode_params& p) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     constexpr int PPW = MONO ? 4 * F : 2 * F;              // packets per workgroup
     const uint32_t pkt0 = blockIdx.x * (uint32_t)PPW;
-    if (p.ab_flags && p.ab_flags[pkt0 >> 3] == 0) return;   // the two-pass kernel decoded this group of 8 already
+    if (p.ab_flags && p.ab_flags[pkt0 >> 3] != 1u) return;   // a two-pass kernel decoded this group of 8 already
     // chunk count must be uniform over the workgroup: every wave derives it from all 2F headers
     int n_any = 0;
     {
@@ -1000,6 +1000,7 @@ struct AbShared {
 // and converts it, fir8_step<.., true>): the inverse of r = (dv >> 1) ^ -(dv & 1) for what rice_step hands back.
 __device__ __forceinline__ int ab_zigzag(int r) { return (int)(((uint32_t)r << 1) ^ (uint32_t)(r >> 31)); }
 
+template <bool RAW>
 __device__ __forceinline__ uint32_t ab_entropy_pass(const alac_decode_params& p, AbShared& sh, const Meta& m, const RiceCfg& rc, int init_hist,
                                     uint32_t startbit, bool stream_on, int g, int sub, int lane, int nchunks, int* flags_out) {
     constexpr int S = 8, LPS = 8;
@@ -1011,21 +1012,26 @@ __device__ __forceinline__ uint32_t ab_entropy_pass(const alac_decode_params& p,
     rs.ra = rs.ra_sync = lds_addr(sh.rings[g]);
     rs.cur = rice_cursor(0, rs.ra);
     uint32_t filled = 0;
-    // lanes with nothing to decode shadow the first active group (same ring, same state): the wave stays in lock step
-    const uint64_t onmask = __builtin_amdgcn_ballot_w64(stream_on);
-    const int src = (stream_on || !onmask) ? lane : (int)__builtin_ctzll(onmask);
+    // Lanes with nothing to decode SHADOW the longest stream of the wave (same ring, same state, results thrown away), so
+    // that the wave stays in lock step on the speculative units: streams that are switched off from the start, and --
+    // from the chunk after its last sample on -- every stream that is shorter than the longest (ragged batches: the last
+    // packet of a file, mixed frame lengths).  Only the chunk in which a stream ends is decoded by the generic loop.
+    const int nmax = __builtin_amdgcn_readfirstlane(wave_max(n_row));
+    const uint64_t longest = __builtin_amdgcn_ballot_w64(stream_on && n_row == nmax);
+    const int srcmax = longest ? (int)__builtin_ctzll(longest) : lane;
+    bool real = stream_on;                       // this lane decodes its own stream
+    const int src = real ? lane : srcmax;
     RiceCfg mc;
     mc.kmod = mirror_i(rc.kmod, src);
     mc.kmask = (1u << mc.kmod) - 1u;
     mc.hist_mult = mirror_i(rc.hist_mult, src);
     mc.rss = mirror_i(rc.rss, src);
-    const int n_eff = mirror_i(m.n, src);
+    int n_eff = mirror_i(m.n, src);
     const int ih = mirror_i(init_hist, src);
     const uint32_t sb = (uint32_t)mirror_i((int)startbit, src);
     const uint32_t* mringp = sh.rings[mirror_i(g, src)];
-    const uint32_t mring = lds_addr(mringp);
-    const int nmin = onmask ? __builtin_amdgcn_readfirstlane(-wave_max(-n_eff)) : 0;
-    const int nmax = __builtin_amdgcn_readfirstlane(wave_max(n_row));
+    uint32_t mring = lds_addr(mringp);
+    int nmin = longest ? __builtin_amdgcn_readfirstlane(-wave_max(-n_eff)) : 0;
     if (nmax > 0) {
         rice_init<LPS>(rs, filled, sb, ih, sh.rings[g], m.base, m.limit, sub, stream_on);
         if (!stream_on) {
@@ -1042,40 +1048,89 @@ __device__ __forceinline__ uint32_t ab_entropy_pass(const alac_decode_params& p,
         sh.ring_filled[g] = filled;
         sh.ring_next[g] = rs.next;
     }
-    for (int c = 0; c < nchunks; c++) {
-        const int i0 = c * AB_CHUNK;
-        int* q = (sub == 0) ? &sh.resq[c & 1][0][g] : &sh.dummy[lane];
-        if (i0 < nmax) {
-            const bool fast_chunk = i0 + AB_CHUNK <= nmin - 1;
-            if (fast_chunk) {
+    uint32_t endpos = 0;
+    int endflags = 0;
+    bool ended = false;
+    int c = 0;
+    while (c < nchunks) {
+        // ---- between stretches: streams that have ended become shadows of the longest one (rare) ----
+        {
+            const int i0 = c * AB_CHUNK;
+            const bool fin = real && i0 >= n_row;
+            if (__builtin_amdgcn_ballot_w64(fin) != 0) {
+                if (fin) {
+                    endpos = rice_bitpos(rs);         // (rice_sync ran at the end of the last chunk)
+                    endflags = flags;
+                    ended = true;
+                    real = false;
+                    if (sub == 0) sh.ring_on[g] = 0u; // no more refills for this ring
+                }
+                const int s2 = fin ? srcmax : lane;
+                rs.w0 = (uint32_t)mirror_i((int)rs.w0, s2);
+                rs.w1 = (uint32_t)mirror_i((int)rs.w1, s2);
+                rs.w2 = (uint32_t)mirror_i((int)rs.w2, s2);
+                rs.cur = (uint32_t)mirror_i((int)rs.cur, s2);
+                rs.ra = (uint32_t)mirror_i((int)rs.ra, s2);
+                rs.ra_sync = (uint32_t)mirror_i((int)rs.ra_sync, s2);
+                rs.next = (uint32_t)mirror_i((int)rs.next, s2);
+                rs.hist = mirror_i(rs.hist, s2);
+                rs.signmod = mirror_i(rs.signmod, s2);
+                rs.zrun = mirror_i(rs.zrun, s2);
+                rs.nforce = (uint32_t)mirror_i((int)rs.nforce, s2);
+                mc.kmod = mirror_i(mc.kmod, s2);
+                mc.kmask = (1u << mc.kmod) - 1u;
+                mc.hist_mult = mirror_i(mc.hist_mult, s2);
+                mc.rss = mirror_i(mc.rss, s2);
+                mring = (uint32_t)mirror_i((int)mring, s2);
+                n_eff = mirror_i(n_eff, s2);
+                nmin = __builtin_amdgcn_readfirstlane(-wave_max(-n_eff));
+            }
+        }
+        // ---- a stretch of chunks up to the one in which the next stream ends: nothing below changes who shadows whom ----
+        const int my_stop = real ? (n_row + AB_CHUNK - 1) / AB_CHUNK : 0x7FFFFFFF;
+        const int c_stop = min(max(__builtin_amdgcn_readfirstlane(-wave_max(-my_stop)), c + 1), nchunks);
+        const RiceCfg kc = mc;
+        const uint32_t kring = mring & ~(uint32_t)RING_MASK;   // (a no-op: rings are 1 KiB aligned -- but the compiler must see it to fold the address into one v_bitop3)
+        const int kn = n_eff, knmin = nmin;
+        const bool kreal = real;
+        for (; c < c_stop; c++) {
+            const int i0 = c * AB_CHUNK;
+            int* q = (sub == 0 && kreal) ? &sh.resq[c & 1][0][g] : &sh.dummy[lane];
+            if (i0 < nmax) {
+                const bool fast_chunk = i0 + AB_CHUNK <= knmin - 1;
+                if (fast_chunk) {
 #pragma unroll
-                for (int u = 0; u < AB_CHUNK; u += SPEC_UNIT) {
-                    const bool redo = !spec_unit<true, S, true>(rs, full_left, mc, mring, q + u * S);
-                    if (redo) {
-                        for (int ii = 0; ii < SPEC_UNIT; ii++)
-                            q[(u + ii) * S] = ab_zigzag(rice_step(rs, mc, n_eff - 1 - (i0 + u + ii), i0 + u + ii, &flags, mring));
+                    for (int u = 0; u < AB_CHUNK; u += SPEC_UNIT) {
+                        const bool redo = !spec_unit<true, S, RAW>(rs, full_left, kc, kring, q + u * S);
+                        if (redo) {
+                            for (int ii = 0; ii < SPEC_UNIT; ii++) {
+                                const int r = rice_step(rs, kc, kn - 1 - (i0 + u + ii), i0 + u + ii, &flags, kring);
+                                q[(u + ii) * S] = RAW ? ab_zigzag(r) : r;
+                            }
+                        }
+                    }
+                } else {      // some stream ends in this chunk (or one sample after it): shadows step with their source
+                    const int qstride = (sub == 0 && kreal) ? S : 0;
+                    for (int ii = 0; ii < AB_CHUNK; ii++) {
+                        const int i = i0 + ii;
+                        int r = 0;
+                        if (i < kn) r = rice_step(rs, kc, kn - 1 - i, i, &flags, kring);
+                        q[ii * qstride] = RAW ? ab_zigzag(r) : r;
                     }
                 }
-            } else {
-                const int qstride = (sub == 0) ? S : 0;
-                for (int ii = 0; ii < AB_CHUNK; ii++) {
-                    const int i = i0 + ii;
-                    int r = 0;
-                    if (i < n_row) r = ab_zigzag(rice_step(rs, mc, n_row - 1 - i, i, &flags, mring));
-                    q[ii * qstride] = r;
-                }
+                rice_sync(rs);
+                if (sub == 0) sh.ring_next[g] = rs.next;
             }
-            rice_sync(rs);
-            if (sub == 0) sh.ring_next[g] = rs.next;
+            wg_sync();  // chunk c is ready for the FIR wave
         }
-        wg_sync();  // chunk c is ready for the FIR wave
     }
     wg_sync();      // final barrier of the pass (every wave executes nchunks + 1 per pass)
     rice_sync(rs);
-    *flags_out = stream_on ? flags : 0;
-    return rice_bitpos(rs);
+    *flags_out = stream_on ? (ended ? endflags : flags) : 0;
+    return ended ? endpos : rice_bitpos(rs);
 }
 
+template <int P>
 __device__ __forceinline__ void ab_entropy_wave(const alac_decode_params& p, uint32_t pkt0, int lane, AbShared& sh, int nch0, int nch1) {
     const int g = lane >> 3, sub = lane & 7;
     const uint32_t pkt = pkt0 + (uint32_t)g;
@@ -1099,7 +1154,7 @@ __device__ __forceinline__ void ab_entropy_wave(const alac_decode_params& p, uin
     for (int ph = 0; ph < (nch1 > 0 ? 2 : 1); ph++) {
         int fl = 0;
         rc.hist_mult = (ph ? mb.ricemod : m.ricemod) * (cfg.rice_history_mult / 4);
-        const uint32_t end = ab_entropy_pass(p, sh, m, rc, cfg.rice_initial_history, ph ? end_a : m.ricebit,
+        const uint32_t end = ab_entropy_pass<P == 8>(p, sh, m, rc, cfg.rice_initial_history, ph ? end_a : m.ricebit,
                                              compressed && (ph == 0 || m.stereo), g, sub, lane, ph ? nch1 : nch0, &fl);
         if (ph == 0) { end_a = end_b = end; flags_a = fl; }
         else { end_b = end; flags_b = fl; }
@@ -1156,19 +1211,21 @@ __device__ __forceinline__ void ab_fir_wave(const alac_decode_params& p, uint32_
     f.w = tap ? (uint32_t)(m.N - j) : 0u;
     f.bpaddr = ((lane & 48) + 2 * (stream_on ? (m.N - 1) & 7 : 0) + par) * 4;
     const int nmax = __builtin_amdgcn_readfirstlane(wave_max(n_row));
-    const int nmin = __builtin_amdgcn_readfirstlane(-wave_max(stream_on ? -m.n : -0x7FFFFFFF));
     const int* qzero = &sh.zeros[0][g];
     for (int c = 0; c < nchunks; c++) {
         const int i0 = c * AB_CHUNK;
         const unsigned long long tb = p.dbg ? clock64() : 0;
         wg_sync();  // wait for chunk c
         if (p.dbg && lane == 0 && c > 0) p.dbg[8 * blockIdx.x + 7] += clock64() - tb;   // diagnostic: time spent in barriers
-        const int* q = stream_on ? &sh.resq[c & 1][0][g] : qzero;
+        // a stream that has ended runs along on zeros (its outputs are not stored); only the chunk in which a stream
+        // ends, and the warm-up, take the masked steps
+        const int* q = (i0 < n_row) ? &sh.resq[c & 1][0][g] : qzero;
+        const bool clean = __builtin_amdgcn_ballot_w64(i0 < n_row && i0 + AB_CHUNK > n_row) == 0;
 #pragma unroll
         for (int half = 0; half < AB_CHUNK / 8; half++) {
             const int ih = i0 + 8 * half;
             if (ih < nmax) {
-                if (ih > 8 && ih + 8 <= nmin) {
+                if (ih > 8 && clean) {
                     int err = q[(8 * half) * S];
 #pragma unroll
                     for (int ii = 0; ii < 8; ii++) {
@@ -1222,17 +1279,17 @@ __device__ __forceinline__ void ab_fir_wave2(const alac_decode_params& p, uint32
     f.bpaddr = ((lane & 48) + 2 * (stream_on ? (m.N - 1) & 7 : 0) + par) * 4;
     f.bphi = stream_on && m.N > 8;
     const int nmax = __builtin_amdgcn_readfirstlane(wave_max(n_row));
-    const int nmin = __builtin_amdgcn_readfirstlane(-wave_max(stream_on ? -m.n : -0x7FFFFFFF));
     const int* qzero = &sh.zeros[0][g];
     for (int c = 0; c < nchunks; c++) {
         const int i0 = c * AB_CHUNK;
         wg_sync();  // wait for chunk c
-        const int* q = stream_on ? &sh.resq[c & 1][0][g] : qzero;
+        const int* q = (i0 < n_row) ? &sh.resq[c & 1][0][g] : qzero;    // see ab_fir_wave
+        const bool clean = __builtin_amdgcn_ballot_w64(i0 < n_row && i0 + AB_CHUNK > n_row) == 0;
 #pragma unroll
         for (int half = 0; half < AB_CHUNK / 8; half++) {
             const int ih = i0 + 8 * half;
             if (ih < nmax) {
-                if (ih > 16 && ih + 8 <= nmin) {
+                if (ih > 16 && clean) {
                     int err = q[(8 * half) * S];
 #pragma unroll
                     for (int ii = 0; ii < 8; ii++) {
@@ -1249,6 +1306,81 @@ __device__ __forceinline__ void ab_fir_wave2(const alac_decode_params& p, uint32
                 }
             }
             sh.outq[c & 1][half][lane] = f.hist[0];
+        }
+    }
+    wg_sync();  // final barrier of the pass
+}
+
+// FIR wave of the 32-tap variant (alac_decode_ab32_kernel): the P16 layout of recon_wave_impl with two tap registers per
+// lane (tap j = l + 16 t of a stream in lane l of its row of 16; fir_fast2, which also does the delta mode N == 31), four
+// packets per wave, two such waves per workgroup (w = 0 / 1: packets 0..3 / 4..7).  The queue carries residuals here.
+__device__ __forceinline__ void ab_fir16_wave(const alac_decode_params& p, uint32_t pkt0, int w, int lane, AbShared& sh, int ph, int nchunks) {
+    constexpr int S = 8;
+    const int l = lane & 15, rowlane0 = lane & 48;
+    const int g = 4 * w + (lane >> 4);
+    const uint32_t pkt = pkt0 + (uint32_t)g;
+    const bool valid = pkt < p.n_packets;
+    alacgpu_cfg_dev cfg;
+    const Meta m = parse_meta(p, pkt, ph, valid, cfg);
+    const bool stream_on = valid && m.status == 0 && !m.esc && (ph == 0 || m.stereo);
+    const int n_row = stream_on ? m.n : 0;
+    Fir<2> f;
+    FirLane2 f2;
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int j = l + 16 * t;
+        f.hist[t] = 0;
+        f.coef[t] = (stream_on && j < m.N) ? (int)(int16_t)peek_bits(m.base, m.limit, m.coefbit + 16u * j, 16) : 0;
+        const bool tp = stream_on && m.N != 31 && j < m.N;
+        f2.tlo[t] = tp ? -1 : 0;
+        f2.thi[t] = tp ? 1 : 0;
+        f2.w[t] = tp ? (uint32_t)(m.N - j) : 0u;
+    }
+    f.base = 0;
+    f.prev = 0;
+    f2.q = stream_on ? m.q : 1;
+    f2.rnd = stream_on ? m.rnd : 0;
+    f2.rss = stream_on ? m.rss : 16;
+    f2.qmask = (1 << f2.q) - 1;
+    f2.delta = stream_on && m.N == 31;
+    f2.bphi = stream_on && m.N != 31 && m.N > 16;
+    f2.bpaddr = (rowlane0 + ((stream_on && m.N != 31) ? (m.N - 1) & 15 : 0)) * 4;
+    const int nmax = __builtin_amdgcn_readfirstlane(wave_max(n_row));
+    const int Nw = __builtin_amdgcn_readfirstlane(wave_max((stream_on && m.N != 31) ? m.N : 0));
+    const int* qzero = &sh.zeros[0][g];
+    for (int c = 0; c < nchunks; c++) {
+        const int i0 = c * AB_CHUNK;
+        wg_sync();  // wait for chunk c
+        const int* q = (i0 < n_row) ? &sh.resq[c & 1][0][g] : qzero;    // see ab_fir_wave
+        const bool clean = __builtin_amdgcn_ballot_w64(i0 < n_row && i0 + AB_CHUNK > n_row) == 0;
+#pragma unroll
+        for (int blk = 0; blk < AB_CHUNK / 16; blk++) {
+            const int ih = i0 + 16 * blk;
+            if (ih < nmax) {
+                if (ih > Nw && ih > 0 && clean) {
+                    f2.hist[0] = f.hist[0]; f2.hist[1] = f.hist[1];
+                    f2.coef[0] = f.coef[0]; f2.coef[1] = f.coef[1];
+                    f2.base = f.base;
+                    f2.prev = f.prev;
+                    int err = q[(16 * blk) * S];
+#pragma unroll
+                    for (int ii = 0; ii < 16; ii++) {
+                        const int en = q[(16 * blk + (ii < 15 ? ii + 1 : ii)) * S];
+                        fir_fast2(f2, err);
+                        err = en;
+                    }
+                    f.hist[0] = f2.hist[0]; f.hist[1] = f2.hist[1];
+                    f.coef[0] = f2.coef[0]; f.coef[1] = f2.coef[1];
+                    f.base = f2.base;
+                    f.prev = f2.prev;
+                } else {
+                    for (int ii = 0; ii < 16; ii++) {
+                        const int i = ih + ii;
+                        if (i < n_row) (void)fir_step<2>(f, q[(16 * blk + ii) * S], i, m.N, m.q, m.rnd, m.rss, l, rowlane0);
+                    }
+                }
+            }
+            sh.outq[c & 1][2 * blk + w][lane] = f.hist[0];   // lane l of a row holds out[last - l] of its stream
         }
     }
     wg_sync();  // final barrier of the pass
@@ -1322,9 +1454,19 @@ struct AbRefill {
     }
 };
 
+// Lane -> (stream g, sample j of a block of 8): P == 8 reads the FIR wave's P8 layout lane for lane; P == 16 lets lane
+// group g = lane >> 3 pick its stream's 16 outputs per block of 16 out of the two FIR waves' P16 layouts, 8 and 8.
+template <int P>
+__device__ __forceinline__ int ab_outq_read(const AbShared& sh, int c, int half, int lane, int g, int j) {
+    if (P == 8) return sh.outq[c & 1][half][lane];        // lane (2t + par) holds out[last - t] of its stream
+    return sh.outq[c & 1][(half & ~1) + (g >> 2)][((g & 3) << 4) + j + 8 * (half & 1)];
+}
+
+template <int P>
 __device__ __forceinline__ void ab_output_wave(const alac_decode_params& p, uint32_t pkt0, int lane, AbShared& sh, int nch0, int nch1) {
-    const int row = lane >> 4, l = lane & 15, par = l & 1, j = l >> 1;
-    const int g = 2 * row + par;
+    const int row = lane >> 4, l = lane & 15, par = l & 1;
+    const int j = P == 8 ? l >> 1 : lane & 7;
+    const int g = P == 8 ? 2 * row + par : lane >> 3;
     const uint32_t pkt = pkt0 + (uint32_t)g;
     const bool valid = pkt < p.n_packets;
     alacgpu_cfg_dev cfg;
@@ -1341,12 +1483,13 @@ __device__ __forceinline__ void ab_output_wave(const alac_decode_params& p, uint
         if (c == 0) { rf.commit(); continue; }
 #pragma unroll
         for (int half = 0; half < AB_CHUNK / 8; half++) {
-            const int ih = (c - 1) * AB_CHUNK + 8 * half;
-            const int cnt = min(8, n_out - ih);
-            if (j >= cnt) continue;
-            const int mine = sh.outq[(c - 1) & 1][half][lane];   // lane (2t + par) holds out[last - t] of its stream
+            const int ih = (c - 1) * AB_CHUNK + (P == 8 ? 8 * half : 16 * (half >> 1));   // start of the FIR layout's block
+            const int jb = P == 8 ? j : j + 8 * (half & 1);                                   // position in that block
+            const int cnt = min(P, n_out - ih);
+            if (jb >= cnt) continue;
+            const int mine = ab_outq_read<P>(sh, c - 1, half, lane, g, j);
             if (m.esc) {                                            // uncompressed: raw samples, both channels now
-                const int i = ih + j;
+                const int i = ih + jb;
                 const int nch = m.stereo ? 2 : 1;
                 for (int ch = 0; ch < nch; ch++) {
                     const uint32_t bp = m.rawbit + (uint32_t)((i * nch + ch) * m.ss);
@@ -1356,7 +1499,7 @@ __device__ __forceinline__ void ab_output_wave(const alac_decode_params& p, uint
                 }
                 if (!m.stereo && m.nc > 1) store_sample(p, m, pcm_slot, (int64_t)i * m.nc + 1, 0);
             } else {
-                const int i = ih + cnt - 1 - j;
+                const int i = ih + cnt - 1 - jb;
                 if (two_pass) {
                     park[i] = mine;
                 } else {                                            // one channel: done
@@ -1378,18 +1521,20 @@ __device__ __forceinline__ void ab_output_wave(const alac_decode_params& p, uint
         for (int h = 0; h < AB_CHUNK / 8; h++) a_cur[h] = a_next[h];
 #pragma unroll
         for (int half = 0; half < AB_CHUNK / 8; half++) {                      // A for chunk c (used after the next barrier)
-            const int ih = c * AB_CHUNK + 8 * half;
-            const int cnt = min(8, n_out - ih);
-            a_next[half] = (two_pass && c < nch1 && j < cnt) ? park[ih + cnt - 1 - j] : 0;
+            const int ih = c * AB_CHUNK + (P == 8 ? 8 * half : 16 * (half >> 1));
+            const int jb = P == 8 ? j : j + 8 * (half & 1);
+            const int cnt = min(P, n_out - ih);
+            a_next[half] = (two_pass && c < nch1 && jb < cnt) ? park[ih + cnt - 1 - jb] : 0;
         }
         if (c == 0) { rf.commit(); continue; }
 #pragma unroll
         for (int half = 0; half < AB_CHUNK / 8; half++) {
-            const int ih = (c - 1) * AB_CHUNK + 8 * half;
-            const int cnt = min(8, n_out - ih);
-            if (!two_pass || j >= cnt) continue;
-            const int i = ih + cnt - 1 - j;
-            const int a = a_cur[half], b = sh.outq[(c - 1) & 1][half][lane];
+            const int ih = (c - 1) * AB_CHUNK + (P == 8 ? 8 * half : 16 * (half >> 1));
+            const int jb = P == 8 ? j : j + 8 * (half & 1);
+            const int cnt = min(P, n_out - ih);
+            if (!two_pass || jb >= cnt) continue;
+            const int i = ih + cnt - 1 - jb;
+            const int a = a_cur[half], b = ab_outq_read<P>(sh, c - 1, half, lane, g, j);
             int left, right;
             if (m.mixweight != 0) {                                 // AlacFile.cs:346-357 / :377-388
                 right = wsub(a, wmul(b, m.mixweight) >> (m.mixshift & 31));
@@ -1405,10 +1550,13 @@ __device__ __forceinline__ void ab_output_wave(const alac_decode_params& p, uint
     }
 }
 
+template <int P>
 __device__ __forceinline__ void ab_kernel_body(const alac_decode_params& p) {
     __shared__ __attribute__((aligned(1024))) AbShared sh;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t pkt0 = blockIdx.x * (uint32_t)AB_PPW;
+    // ab_flags[group]: 0 = decoded by alac_decode_ab_kernel, 2 = by alac_decode_ab32_kernel, 1 = left to the split kernel
+    if (P == 16 && (!p.ab_flags || p.ab_flags[blockIdx.x] == 0u)) return;
     // every wave reads all 8 headers: pass lengths (uniform over the workgroup) and whether the P8 layout fits
     int n0 = 0, n1 = 0;
     bool bad = false, wide_lane = false;
@@ -1421,14 +1569,18 @@ __device__ __forceinline__ void ab_kernel_body(const alac_decode_params& p) {
         const bool ok = v && ma.status == 0;
         n0 = ok ? ma.n : 0;
         n1 = (ok && !ma.esc && ma.stereo) ? ma.n : 0;
-        bad = ok && !ma.esc && (ma.N < 1 || ma.N > 16 || (ma.stereo && (mb.N < 1 || mb.N > 16)));
+        bad = ok && !ma.esc && (ma.N < 1 || ma.N > (P == 8 ? 16 : 31) || (ma.stereo && (mb.N < 1 || mb.N > (P == 8 ? 16 : 31))));
         wide_lane = ok && !ma.esc && (ma.N > 8 || (ma.stereo && mb.N > 8));
         // the parking place needs two ints per sample in the slot (always true for a two-channel stream cfg)
         bad = bad || (n1 > 0 && (uint64_t)2 * (uint64_t)ma.n > p.slot_ints);
     }
     const bool fallback = __builtin_amdgcn_ballot_w64(bad) != 0;
     const bool wide = __builtin_amdgcn_ballot_w64(wide_lane) != 0;   // some stream has more than 8 taps: two taps per lane
-    if (p.ab_flags && threadIdx.x == 0) p.ab_flags[blockIdx.x] = fallback ? 1u : 0u;
+    if (P == 8) {
+        if (p.ab_flags && threadIdx.x == 0) p.ab_flags[blockIdx.x] = fallback ? 1u : 0u;
+    } else {
+        if (!fallback && threadIdx.x == 0) p.ab_flags[blockIdx.x] = 2u;
+    }
     if (fallback) return;
     const int nch0 = (__builtin_amdgcn_readfirstlane(wave_max(n0)) + AB_CHUNK - 1) / AB_CHUNK;
     const int nch1 = (__builtin_amdgcn_readfirstlane(wave_max(n1)) + AB_CHUNK - 1) / AB_CHUNK;
@@ -1443,10 +1595,12 @@ __device__ __forceinline__ void ab_kernel_body(const alac_decode_params& p) {
     wg_sync();
     if (wave == 0) {
         __builtin_amdgcn_s_setprio(ALAC_ENTROPY_PRIO);
-        ab_entropy_wave(p, pkt0, lane, sh, nch0, nch1);
+        ab_entropy_wave<P>(p, pkt0, lane, sh, nch0, nch1);
         if (p.dbg && lane == 0) p.dbg[8 * blockIdx.x + 2] = clock64();
     } else if (wave == 1) {
-        ab_output_wave(p, pkt0, lane, sh, nch0, nch1);
+        ab_output_wave<P>(p, pkt0, lane, sh, nch0, nch1);
+    } else if (P == 16) {   // (consecutive four-wave workgroups of a CU start on consecutive SIMDs: no role rotation needed)
+        for (int ph = 0; ph < (nch1 > 0 ? 2 : 1); ph++) ab_fir16_wave(p, pkt0, wave - 2, lane, sh, ph, ph ? nch1 : nch0);
     } else {
         if (__builtin_expect(!wide, 1)) {
             for (int ph = 0; ph < (nch1 > 0 ? 2 : 1); ph++) ab_fir_wave(p, pkt0, lane, sh, ph, ph ? nch1 : nch0);
@@ -1461,7 +1615,9 @@ __device__ __forceinline__ void ab_kernel_body(const alac_decode_params& p) {
 // The 4- and 8-wave-per-workgroup kernels serve big batches, where exactly-full occupancy is a cliff (a
 // workgroup that does not fit waits for a whole round): cap them at 80 VGPRs = 6 waves per SIMD.  The small-batch
 // kernels never fill the CU and keep the unconstrained allocation.
-extern "C" __global__ __launch_bounds__(192) void alac_decode_ab_kernel(alac_decode_params p) { ab_kernel_body(p); }
+extern "C" __global__ __launch_bounds__(192) void alac_decode_ab_kernel(alac_decode_params p) { ab_kernel_body<8>(p); }
+// LPC orders up to 31 (and the delta mode): two FIR waves in the 16-lane layout with two tap registers, four packets each
+extern "C" __global__ __launch_bounds__(256) void alac_decode_ab32_kernel(alac_decode_params p) { ab_kernel_body<16>(p); }
 extern "C" __global__ __launch_bounds__(128) void alac_decode_split1_kernel(alac_decode_params p) { split_kernel_body<1, false>(p); }
 extern "C" __global__ __launch_bounds__(192) void alac_decode_split2_kernel(alac_decode_params p) { split_kernel_body<2, false>(p); }
 extern "C" __global__ __launch_bounds__(320, 6) void alac_decode_split4_kernel(alac_decode_params p) { split_kernel_body<4, false>(p); }

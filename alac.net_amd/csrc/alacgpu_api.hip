@@ -89,7 +89,9 @@ int launch(alacgpu_ctx* ctx, const alac_decode_params& p_in, hipStream_t stream)
         alac_decode_params args = p;
         void* kargs[] = {&args};
         HIP_TRY(ctx, hipLaunchKernel((const void*)alac_decode_ab_kernel, dim3((uint32_t)groups), dim3(192), kargs, 0, stream));
-        variant = split_auto;   // the fallback for what it flagged
+        // what it flagged: LPC orders up to 31 -> the 32-tap arrangement of the same kernel; the rest -> a split kernel
+        HIP_TRY(ctx, hipLaunchKernel((const void*)alac_decode_ab32_kernel, dim3((uint32_t)groups), dim3(256), kargs, 0, stream));
+        variant = split_auto;
     }
     // Pick the kernel and its geometry.
     const void* fn = nullptr;

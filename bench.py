@@ -193,8 +193,9 @@ def main():
         if all_mono and (args.variant or auto) in (3, 4):
             kernel_name = kernel_name.replace("_kernel", "_mono_kernel")
         if (args.variant or auto) == 5 and args.config == 5:
-            # LPC orders above 16: the two-pass kernel hands (nearly) every workgroup to the split kernel launched behind it
-            kernel_name = "alac_decode_split%d_kernel (behind alac_decode_ab_kernel)" % (4 if split_auto == 4 else 2)
+            # LPC orders above 16 in (nearly) every group of 8 packets: the work is done by the 32-tap arrangement launched
+            # behind the main two-pass kernel
+            kernel_name = "alac_decode_ab32_kernel (behind alac_decode_ab_kernel)"
         # HBM traffic comes from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read in-process):
         # the committed measurement of the same workload + kernel, see profiles/
         traffic = None
