@@ -73,7 +73,10 @@ int launch(alacgpu_ctx* ctx, const alac_decode_params& p_in, hipStream_t stream)
     // per packet).  Measured on MI355X, cfg2, small / big workgroup: 4096 packets 0.99 / 1.08 ms, 8192 packets
     // 2.14 / 1.37 ms, 32768 packets 7.1 / 6.2 ms; mono cfg4: 8192 packets 0.67 / 0.69 ms, 16384 packets 1.60 / 0.99 ms.
     const int split_auto = p.n_packets > (ctx->all_mono ? 10240u : 5120u) ? 4 : 3;
-    if (variant == 0) variant = ctx->all_mono ? split_auto : 5;
+    // One-channel cfgs finish in the two-pass kernel's first pass (8 packets per workgroup, no parking); measured on cfg4,
+    // two-pass / split: 1024 packets 0.44 / 0.51 ms, 4096 0.44 / 0.58, 8192 0.57 / 0.59, 16384 1.33 / 0.93 (more
+    // workgroups than fit at once: the 16-packet split workgroup wins), 32768 2.42 / 2.69.
+    if (variant == 0) variant = (ctx->all_mono && p.n_packets > 10240u) ? 4 : 5;
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
     if (variant == 5) {
         const size_t groups = ((size_t)p.n_packets + 7) / 8;
