@@ -518,3 +518,33 @@ def test_speculative_tiers_on_full_length_streams(pkg, oracle, synth, variant, i
     assert (o[3] == 0).all()
     assert_same(g, o, b["stream_cfgs"], None)
     assert np.array_equal(g[0][:, :8192], b["pcm"][:, :8192])
+
+
+@pytest.mark.parametrize("variant", [4, 5])
+@pytest.mark.parametrize("stereo", [True, False])
+@pytest.mark.parametrize("orders", [(1, 9), (9, 17), (17, 32)])
+def test_ragged_batches_long_and_short_packets_share_a_workgroup(pkg, oracle, synth, variant, stereo, orders):
+    # Most packets are full frames, a few end early at assorted places (chunk boundaries, one sample either side of
+    # them, one sample long): in the two-pass kernels a stream that ends becomes a shadow of the longest stream of its wave
+    # and the speculative units go on -- in all three FIR arrangements (one tap per lane, two taps per lane, the 32-tap
+    # kernel with the delta mode), both passes, and for one-channel packets.
+    count = 64
+    rng = np.random.default_rng(orders[0] * 7 + stereo)
+    d = synth.packet_descs(count, max_samples_per_frame=4096, sample_size=16, stereo=int(stereo))
+    n = np.full(count, 4096)
+    short = [1, 2, 31, 32, 33, 63, 64, 65, 1000, 2047, 2048, 2049, 4064, 4065, 4095, 500]
+    n[rng.choice(count, len(short), replace=False)] = short
+    n[8:16] = [4096, 4096, 777, 4096, 4096, 4096, 4096, 4096]   # one short packet among seven long ones
+    n[16:24] = 1234                                               # a workgroup of equal, short packets
+    d["n"] = n
+    d["pred_order"] = rng.integers(orders[0], orders[1], (count, 2))
+    sig = synth.default_signal(2718)
+    sig["silence_prob"] = 0.1
+    b = synth.make_batch(d, sig, want_pcm=True)
+    b.update(stream_cfgs=[(4096, 16, 40, 10, 14, 2 if stereo else 1)], cfg_idx=None)
+    g, o = run_both(pkg, oracle, b, variant=variant)
+    assert (o[3] == 0).all()
+    assert_same(g, o, b["stream_cfgs"], None)
+    for p in range(count):
+        cnt = int(n[p]) * (2 if stereo else 1)
+        assert np.array_equal(g[0][p, :cnt], b["pcm"][p, :cnt])
