@@ -1347,6 +1347,7 @@ __device__ __forceinline__ void ab_fir16_wave(const alac_decode_params& p, uint3
     f2.bpaddr = (rowlane0 + ((stream_on && m.N != 31) ? (m.N - 1) & 15 : 0)) * 4;
     const int nmax = __builtin_amdgcn_readfirstlane(wave_max(n_row));
     const int Nw = __builtin_amdgcn_readfirstlane(wave_max((stream_on && m.N != 31) ? m.N : 0));
+    const bool taps_ok = __builtin_amdgcn_ballot_w64(stream_on && m.N < 1) == 0;   // fir_fast2 wants N >= 1 in every row
     const int* qzero = &sh.zeros[0][g];
     for (int c = 0; c < nchunks; c++) {
         const int i0 = c * AB_CHUNK;
@@ -1357,7 +1358,7 @@ __device__ __forceinline__ void ab_fir16_wave(const alac_decode_params& p, uint3
         for (int blk = 0; blk < AB_CHUNK / 16; blk++) {
             const int ih = i0 + 16 * blk;
             if (ih < nmax) {
-                if (ih > Nw && ih > 0 && clean) {
+                if (ih > Nw && ih > 0 && clean && taps_ok) {
                     f2.hist[0] = f.hist[0]; f2.hist[1] = f.hist[1];
                     f2.coef[0] = f.coef[0]; f2.coef[1] = f.coef[1];
                     f2.base = f.base;
@@ -1569,7 +1570,8 @@ __device__ __forceinline__ void ab_kernel_body(const alac_decode_params& p) {
         const bool ok = v && ma.status == 0;
         n0 = ok ? ma.n : 0;
         n1 = (ok && !ma.esc && ma.stereo) ? ma.n : 0;
-        bad = ok && !ma.esc && (ma.N < 1 || ma.N > (P == 8 ? 16 : 31) || (ma.stereo && (mb.N < 1 || mb.N > (P == 8 ? 16 : 31))));
+        // the main kernel takes LPC orders 1..16; the 32-tap one every order (0 and its neighbours at the masked steps' pace)
+        bad = P == 8 && ok && !ma.esc && (ma.N < 1 || ma.N > 16 || (ma.stereo && (mb.N < 1 || mb.N > 16)));
         wide_lane = ok && !ma.esc && (ma.N > 8 || (ma.stereo && mb.N > 8));
         // the parking place needs two ints per sample in the slot (always true for a two-channel stream cfg)
         bad = bad || (n1 > 0 && (uint64_t)2 * (uint64_t)ma.n > p.slot_ints);
@@ -1592,12 +1594,21 @@ __device__ __forceinline__ void ab_kernel_body(const alac_decode_params& p) {
             p.dbg[8 * blockIdx.x + 0] = clock64();
         }
     }
+    // Who does what: entropy, output, FIR in wave order.  The dispatcher puts the waves of a workgroup on consecutive SIMDs of
+    // its round (0, 2, 1, 3) and usually starts the next workgroup of the CU one SIMD further (HW_ID stamps: (2,1,3) then
+    // (1,3,0) on 224 of 256 CUs), so each heavy wave (entropy, FIR) shares a SIMD with an output wave at most.  When two
+    // heavy waves of different workgroups do share one the launch takes 30 % longer -- and where the dispatcher starts
+    // depends on what ran before: see DESIGN.md ("placement").
+    if (p.dbg && lane == 0 && wave < 3)
+        p.dbg[8 * blockIdx.x + (wave == 0 ? 3 : wave == 1 ? 5 : 6)] =
+            ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492);
+    const int role = wave;
     wg_sync();
-    if (wave == 0) {
+    if (role == 0) {
         __builtin_amdgcn_s_setprio(ALAC_ENTROPY_PRIO);
         ab_entropy_wave<P>(p, pkt0, lane, sh, nch0, nch1);
         if (p.dbg && lane == 0) p.dbg[8 * blockIdx.x + 2] = clock64();
-    } else if (wave == 1) {
+    } else if (role == 1) {
         ab_output_wave<P>(p, pkt0, lane, sh, nch0, nch1);
     } else if (P == 16) {   // (consecutive four-wave workgroups of a CU start on consecutive SIMDs: no role rotation needed)
         for (int ph = 0; ph < (nch1 > 0 ? 2 : 1); ph++) ab_fir16_wave(p, pkt0, wave - 2, lane, sh, ph, ph ? nch1 : nch0);

@@ -92,7 +92,11 @@ int launch(alacgpu_ctx* ctx, const alac_decode_params& p_in, hipStream_t stream)
         alac_decode_params args = p;
         void* kargs[] = {&args};
         HIP_TRY(ctx, hipLaunchKernel((const void*)alac_decode_ab_kernel, dim3((uint32_t)groups), dim3(192), kargs, 0, stream));
-        // what it flagged: LPC orders up to 31 -> the 32-tap arrangement of the same kernel; the rest -> a split kernel
+        // what it flagged -> the 32-tap arrangement of the same kernel, which takes every LPC order.  Nothing is left for
+        // the split kernel launched last (a two-channel packet passes the header check only in a two-channel stream cfg,
+        // where its slot has room for parking), but the launch stays: it is the net under that argument, and without it
+        // the NEXT batch's main kernel ran 30 % slower in a decode loop (1.05 vs 0.81 ms on cfg2) -- the dispatcher
+        // then starts its workgroups on other SIMDs and heavy waves end up sharing one ("placement").
         HIP_TRY(ctx, hipLaunchKernel((const void*)alac_decode_ab32_kernel, dim3((uint32_t)groups), dim3(256), kargs, 0, stream));
         variant = split_auto;
     }

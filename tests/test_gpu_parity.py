@@ -333,17 +333,17 @@ def test_packed_output_equals_format_samples(pkg, oracle, synth, cfg, variant):
 
 @pytest.mark.parametrize("out_format", [0, 1])
 def test_two_pass_kernel_and_its_fallback_share_a_batch(pkg, oracle, synth, out_format):
-    # groups of 8 packets alternate between what the two-pass kernel takes (orders 1..8) and what it hands to the split
-    # kernel behind it (order 16 somewhere in the group); one-channel, uncompressed and short packets mixed in; the last
-    # group is partly filled
+    # groups of 8 packets alternate between what the main two-pass kernel takes (orders 1..8, or 16 somewhere in the
+    # group: two taps per lane) and what it hands to the 32-tap kernel behind it (order 24, 31 = delta mode, or 0 somewhere
+    # in the group); one-channel, uncompressed and short packets mixed in; the last group is partly filled
     count = 8 * 9 + 5
     rng = np.random.default_rng(4711)
     d = synth.packet_descs(count, n=2048, max_samples_per_frame=4096, sample_size=16, stereo=1)
     d["n"] = rng.integers(1, 2049, count)
     d["n"][::2] = 2048
     d["pred_order"] = rng.integers(1, 9, (count, 2))
-    for g in range(1, 10, 2):                       # every other group: one packet with a long predictor
-        d["pred_order"][min(8 * g + int(rng.integers(0, 8)), count - 1), int(rng.integers(0, 2))] = 16
+    for g in range(1, 10, 2):                       # every other group: one packet with a long (or no) predictor
+        d["pred_order"][min(8 * g + int(rng.integers(0, 8)), count - 1), int(rng.integers(0, 2))] = [16, 24, 31, 0, 17][g // 2]
     d["stereo"][rng.random(count) < 0.15] = 0       # channels field 0 in a two-channel file
     d["escape"] = rng.random(count) < 0.1
     sig = synth.default_signal(5)
@@ -548,3 +548,4 @@ def test_ragged_batches_long_and_short_packets_share_a_workgroup(pkg, oracle, sy
     for p in range(count):
         cnt = int(n[p]) * (2 if stereo else 1)
         assert np.array_equal(g[0][p, :cnt], b["pcm"][p, :cnt])
+
