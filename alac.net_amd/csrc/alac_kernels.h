@@ -44,6 +44,10 @@ struct alac_decode_params {
     // flagged 1 and writes 2 where it decoded one; the split kernels, when handed the array, decode only the groups
     // still flagged 1.  Null: no such protocol (a kernel does every packet).
     uint32_t* ab_flags;
+    // Two-pass kernels: one counter per CU (index: XCC_ID, SE_ID, SH_ID, CU_ID), bumped by every workgroup that starts
+    // there; its value, the workgroup's turn on the CU, rotates the roles of the workgroup's waves over the SIMDs.
+    // 2048 entries, never reset (only the value modulo 4 matters).  Null: roles in wave order.
+    uint32_t* cu_arrivals;
 };
 
 #ifdef __HIPCC__

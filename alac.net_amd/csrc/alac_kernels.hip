@@ -1582,6 +1582,14 @@ __device__ __forceinline__ void ab_kernel_body(const alac_decode_params& p) {
         if (p.ab_flags && threadIdx.x == 0) p.ab_flags[blockIdx.x] = fallback ? 1u : 0u;
     } else {
         if (!fallback && threadIdx.x == 0) p.ab_flags[blockIdx.x] = 2u;
+        // Nothing is launched behind this kernel in auto mode.  What it cannot take would be a two-channel packet without
+        // room for parking in its slot -- which cannot pass the header check (parse_meta: two channels only in a
+        // two-channel stream cfg, and then 2 n <= slot_ints).  Should that ever change, fail loudly rather than skip:
+        if (fallback && threadIdx.x < (unsigned)AB_PPW && pkt0 + threadIdx.x < p.n_packets) {
+            p.status[pkt0 + threadIdx.x] = ALACGPU_ST_UNSUPPORTED_PARAMS_D;
+            if (p.out_bytes) p.out_bytes[pkt0 + threadIdx.x] = 0;
+            if (p.out_samples) p.out_samples[pkt0 + threadIdx.x] = 0;
+        }
     }
     if (fallback) return;
     const int nch0 = (__builtin_amdgcn_readfirstlane(wave_max(n0)) + AB_CHUNK - 1) / AB_CHUNK;
@@ -1594,15 +1602,31 @@ __device__ __forceinline__ void ab_kernel_body(const alac_decode_params& p) {
             p.dbg[8 * blockIdx.x + 0] = clock64();
         }
     }
-    // Who does what: entropy, output, FIR in wave order.  The dispatcher puts the waves of a workgroup on consecutive SIMDs of
-    // its round (0, 2, 1, 3) and usually starts the next workgroup of the CU one SIMD further (HW_ID stamps: (2,1,3) then
-    // (1,3,0) on 224 of 256 CUs), so each heavy wave (entropy, FIR) shares a SIMD with an output wave at most.  When two
-    // heavy waves of different workgroups do share one the launch takes 30 % longer -- and where the dispatcher starts
-    // depends on what ran before: see DESIGN.md ("placement").
+    // Who does what.  A heavy wave (entropy, FIR) should share its SIMD with an output wave at most: where two heavy waves of
+    // different workgroups share one, those workgroups take 30 % longer, and the launch ends with its slowest workgroup.
+    // Where the dispatcher puts the waves depends on what ran before (even on the kernel launched before this one: measured,
+    // one XCD's worth of CUs ended up with clashing pairs and cfg2 took 1.05 instead of 0.81 ms), so the roles do not go
+    // by wave index: every workgroup has one wave on each of the CU's four SIMDs (the main kernel brings a fourth wave
+    // for that, which leaves at once), takes its turn k on the CU from a counter, and puts entropy on SIMD k, output on
+    // k + 1, FIR on k + 2 (the 32-tap kernel: its FIR waves on k + 2 and k + 3).  Workgroups with consecutive turns so
+    // never pair two heavy waves; four per CU load every SIMD alike.
     if (p.dbg && lane == 0 && wave < 3)
         p.dbg[8 * blockIdx.x + (wave == 0 ? 3 : wave == 1 ? 5 : 6)] =
             ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492);
-    const int role = wave;
+    int role = wave;
+    if (p.cu_arrivals) {
+        const uint32_t hw = __builtin_amdgcn_s_getreg(63492);                       // HW_ID
+        const uint32_t my_simd = (hw >> 4) & 3u;
+        if (threadIdx.x == 0) {
+            const uint32_t cu = ((__builtin_amdgcn_s_getreg(63508) & 7u) << 8) | (((hw >> 13) & 7u) << 5) | (((hw >> 12) & 1u) << 4) | ((hw >> 8) & 15u);
+            sh.ring_next[7] = atomicAdd(&p.cu_arrivals[cu], 1u);                    // (ring_next / ring_on are free until the first pass)
+        }
+        if (lane == 0) sh.ring_on[wave] = my_simd;
+        wg_sync();
+        const uint32_t used = (1u << sh.ring_on[0]) | (1u << sh.ring_on[1]) | (1u << sh.ring_on[2]) | (1u << sh.ring_on[3]);
+        if (used == 15u) role = (int)((my_simd - sh.ring_next[7]) & 3u);            // (else: not one wave per SIMD -- wave order)
+    }
+    if (P == 8 && role == 3) return;     // the main kernel's fourth wave was only there to claim the fourth SIMD
     wg_sync();
     if (role == 0) {
         __builtin_amdgcn_s_setprio(ALAC_ENTROPY_PRIO);
@@ -1610,8 +1634,8 @@ __device__ __forceinline__ void ab_kernel_body(const alac_decode_params& p) {
         if (p.dbg && lane == 0) p.dbg[8 * blockIdx.x + 2] = clock64();
     } else if (role == 1) {
         ab_output_wave<P>(p, pkt0, lane, sh, nch0, nch1);
-    } else if (P == 16) {   // (consecutive four-wave workgroups of a CU start on consecutive SIMDs: no role rotation needed)
-        for (int ph = 0; ph < (nch1 > 0 ? 2 : 1); ph++) ab_fir16_wave(p, pkt0, wave - 2, lane, sh, ph, ph ? nch1 : nch0);
+    } else if (P == 16) {
+        for (int ph = 0; ph < (nch1 > 0 ? 2 : 1); ph++) ab_fir16_wave(p, pkt0, role - 2, lane, sh, ph, ph ? nch1 : nch0);
     } else {
         if (__builtin_expect(!wide, 1)) {
             for (int ph = 0; ph < (nch1 > 0 ? 2 : 1); ph++) ab_fir_wave(p, pkt0, lane, sh, ph, ph ? nch1 : nch0);
@@ -1626,7 +1650,7 @@ __device__ __forceinline__ void ab_kernel_body(const alac_decode_params& p) {
 // The 4- and 8-wave-per-workgroup kernels serve big batches, where exactly-full occupancy is a cliff (a
 // workgroup that does not fit waits for a whole round): cap them at 80 VGPRs = 6 waves per SIMD.  The small-batch
 // kernels never fill the CU and keep the unconstrained allocation.
-extern "C" __global__ __launch_bounds__(192) void alac_decode_ab_kernel(alac_decode_params p) { ab_kernel_body<8>(p); }
+extern "C" __global__ __launch_bounds__(256) void alac_decode_ab_kernel(alac_decode_params p) { ab_kernel_body<8>(p); }
 // LPC orders up to 31 (and the delta mode): two FIR waves in the 16-lane layout with two tap registers, four packets each
 extern "C" __global__ __launch_bounds__(256) void alac_decode_ab32_kernel(alac_decode_params p) { ab_kernel_body<16>(p); }
 extern "C" __global__ __launch_bounds__(128) void alac_decode_split1_kernel(alac_decode_params p) { split_kernel_body<1, false>(p); }

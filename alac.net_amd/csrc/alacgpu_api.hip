@@ -25,6 +25,7 @@ struct alacgpu_ctx {
     uint32_t out_format = 0;           // 0 int32 per sample, 1 packed little-endian PCM
     bool all_mono = false;             // every stream cfg has one channel -> the *_mono kernels
     int variant = 0;                   // 0 auto, 1 fused (v1), 2/3/4 split with 1/2/4 reconstruction waves, 5 two-pass
+    uint32_t* d_cu_arrivals = nullptr; // two-pass kernels: per-CU workgroup counters (alac_decode_params::cu_arrivals)
     uint32_t* d_ab_flags = nullptr;    // two-pass kernel -> fallback launch protocol (one flag per 8 packets), grow-only
     size_t ab_flags_n = 0;
     // grow-only device workspace for the host-buffer entry points
@@ -63,16 +64,12 @@ int launch(alacgpu_ctx* ctx, const alac_decode_params& p_in, hipStream_t stream)
     if (p_in.n_packets == 0) return ALACGPU_OK;
     alac_decode_params p = p_in;
     p.ab_flags = nullptr;
+    p.cu_arrivals = ctx->d_cu_arrivals;
     int variant = ctx->variant;
-    // auto, two-channel stream cfgs: the two-pass kernel (no Rice pre-scan; cfg2 0.99 -> 0.8x ms), which decodes the
-    // groups of 8 packets whose streams fit its layout (LPC order 1..8) and flags the others for a split kernel
-    // launched right behind it on the same stream.
-    // auto, fallback and one-channel cfgs: while every workgroup is resident at once (up to ~5 per CU) the small
-    // workgroup (1 entropy + 2 reconstruction waves: 4 stereo / 8 mono packets) has the shortest critical path; bigger
-    // batches are throughput bound and do better with twice the packets per workgroup (half as many entropy waves
-    // per packet).  Measured on MI355X, cfg2, small / big workgroup: 4096 packets 0.99 / 1.08 ms, 8192 packets
-    // 2.14 / 1.37 ms, 32768 packets 7.1 / 6.2 ms; mono cfg4: 8192 packets 0.67 / 0.69 ms, 16384 packets 1.60 / 0.99 ms.
-    const int split_auto = p.n_packets > (ctx->all_mono ? 10240u : 5120u) ? 4 : 3;
+    // auto: the two-pass kernels (no Rice pre-scan; cfg2 0.99 -> 0.81 ms).  The main one decodes the groups of 8 packets
+    // whose streams have LPC order 1..16 and flags the others for the 32-tap arrangement launched right behind it on the
+    // same stream.  The split kernels (variants 2..4: 2 / 4 / 8 packets per workgroup, twice that for one-channel cfgs)
+    // remain as A/B references, and variant 4 as the choice for one-channel cfgs in very big batches.
     // One-channel cfgs finish in the two-pass kernel's first pass (8 packets per workgroup, no parking); measured on cfg4,
     // two-pass / split: 1024 packets 0.44 / 0.51 ms, 4096 0.44 / 0.58, 8192 0.57 / 0.59, 16384 1.33 / 0.93 (more
     // workgroups than fit at once: the 16-packet split workgroup wins), 32768 2.42 / 2.69.
@@ -91,14 +88,16 @@ int launch(alacgpu_ctx* ctx, const alac_decode_params& p_in, hipStream_t stream)
         p.ab_flags = ctx->d_ab_flags;
         alac_decode_params args = p;
         void* kargs[] = {&args};
-        HIP_TRY(ctx, hipLaunchKernel((const void*)alac_decode_ab_kernel, dim3((uint32_t)groups), dim3(192), kargs, 0, stream));
-        // what it flagged -> the 32-tap arrangement of the same kernel, which takes every LPC order.  Nothing is left for
-        // the split kernel launched last (a two-channel packet passes the header check only in a two-channel stream cfg,
-        // where its slot has room for parking), but the launch stays: it is the net under that argument, and without it
-        // the NEXT batch's main kernel ran 30 % slower in a decode loop (1.05 vs 0.81 ms on cfg2) -- the dispatcher
-        // then starts its workgroups on other SIMDs and heavy waves end up sharing one ("placement").
+        HIP_TRY(ctx, hipLaunchKernel((const void*)alac_decode_ab_kernel, dim3((uint32_t)groups), dim3(256), kargs, 0, stream));
+        // what it flagged -> the 32-tap arrangement of the same kernel, which takes every LPC order and so everything that
+        // is left (a two-channel packet passes the header check only in a two-channel stream cfg, where its slot has room
+        // for parking; the kernel reports a status if that ever fails).  Variants 2..4 remain as A/B references and for
+        // one-channel cfgs in very big batches.
         HIP_TRY(ctx, hipLaunchKernel((const void*)alac_decode_ab32_kernel, dim3((uint32_t)groups), dim3(256), kargs, 0, stream));
-        variant = split_auto;
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
+        ctx->timed = true;
+        return ALACGPU_OK;
     }
     // Pick the kernel and its geometry.
     const void* fn = nullptr;
@@ -210,6 +209,8 @@ int alacgpu_create(const alacgpu_cfg* cfgs, uint32_t n_cfgs, int device, alacgpu
         if (hipMemcpy(ctx->d_cfgs, cfgs, sizeof(alacgpu_cfg) * n_cfgs, hipMemcpyHostToDevice) != hipSuccess) { rc = ALACGPU_ERR_HIP; break; }
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { rc = ALACGPU_ERR_HIP; break; }
         if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) { rc = ALACGPU_ERR_HIP; break; }
+        if (hipMalloc((void**)&ctx->d_cu_arrivals, 2048 * sizeof(uint32_t)) != hipSuccess ||
+            hipMemset(ctx->d_cu_arrivals, 0, 2048 * sizeof(uint32_t)) != hipSuccess) { rc = ALACGPU_ERR_HIP; break; }
     } while (0);
     if (rc != ALACGPU_OK) {
         alacgpu_destroy(ctx);
@@ -224,6 +225,7 @@ void alacgpu_destroy(alacgpu_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
+    if (ctx->d_cu_arrivals) (void)hipFree(ctx->d_cu_arrivals);
     if (ctx->d_ab_flags) (void)hipFree(ctx->d_ab_flags);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     if (ctx->d_cfgs) (void)hipFree(ctx->d_cfgs);

@@ -332,7 +332,7 @@ def test_packed_output_equals_format_samples(pkg, oracle, synth, cfg, variant):
 
 
 @pytest.mark.parametrize("out_format", [0, 1])
-def test_two_pass_kernel_and_its_fallback_share_a_batch(pkg, oracle, synth, out_format):
+def test_both_two_pass_kernels_share_a_batch(pkg, oracle, synth, out_format):
     # groups of 8 packets alternate between what the main two-pass kernel takes (orders 1..8, or 16 somewhere in the
     # group: two taps per lane) and what it hands to the 32-tap kernel behind it (order 24, 31 = delta mode, or 0 somewhere
     # in the group); one-channel, uncompressed and short packets mixed in; the last group is partly filled
