@@ -1624,7 +1624,12 @@ __device__ __forceinline__ void ab_kernel_body(const alac_decode_params& p) {
         if (lane == 0) sh.ring_on[wave] = my_simd;
         wg_sync();
         const uint32_t used = (1u << sh.ring_on[0]) | (1u << sh.ring_on[1]) | (1u << sh.ring_on[2]) | (1u << sh.ring_on[3]);
-        if (used == 15u) role = (int)((my_simd - sh.ring_next[7]) & 3u);            // (else: not one wave per SIMD -- wave order)
+        if (used == 15u) {                                                          // (else: not one wave per SIMD -- wave order)
+            // the 32-tap kernel has four working waves, two of them FIR: with up to two workgroups per CU a step of two
+            // SIMDs per turn pairs every FIR wave with an entropy or an output wave instead of another FIR wave
+            const uint32_t step = (P == 16 && gridDim.x <= 512u) ? 2u : 1u;
+            role = (int)((my_simd - step * sh.ring_next[7]) & 3u);
+        }
     }
     if (P == 8 && role == 3) return;     // the main kernel's fourth wave was only there to claim the fourth SIMD
     wg_sync();
