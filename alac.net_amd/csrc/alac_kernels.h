@@ -54,8 +54,8 @@ struct alac_decode_params {
 extern "C" __global__ void alac_decode_packets_kernel(alac_decode_params p);   // v1: fused, 2 packets / 64-thread WG
 extern "C" __global__ void alac_decode_split1_kernel(alac_decode_params p);    // v2: 1 entropy + 1 recon wave, 2 packets
 extern "C" __global__ void alac_decode_split2_kernel(alac_decode_params p);    // v2: 1 entropy + 2 recon waves, 4 packets
-extern "C" __global__ void alac_decode_ab_kernel(alac_decode_params p);        // v3: two passes (channel A, then B), 8 stereo packets / 192-thread WG
-extern "C" __global__ void alac_decode_ab32_kernel(alac_decode_params p);      // v3 for LPC orders 17..31: two FIR waves (16-lane layout, 2 tap registers) / 256-thread WG
+extern "C" __global__ void alac_decode_ab_kernel(alac_decode_params p);        // v3: two passes (channel A, then B), 8 packets / 256-thread WG (three working waves), LPC orders 1..16
+extern "C" __global__ void alac_decode_ab32_kernel(alac_decode_params p);      // v3 for everything else (LPC orders 17..31, delta mode, order 0): two FIR waves (16-lane layout, 2 tap registers) / 256-thread WG
 extern "C" __global__ void alac_decode_split4_kernel(alac_decode_params p);    // v2: 1 entropy + 4 recon waves, 8 packets
 extern "C" __global__ void alac_decode_split2_mono_kernel(alac_decode_params p);  // one-channel streams: 8 packets / WG
 extern "C" __global__ void alac_decode_split4_mono_kernel(alac_decode_params p);  // one-channel streams: 16 packets / WG

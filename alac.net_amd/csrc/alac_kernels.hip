@@ -7,9 +7,9 @@
 // :338-421), integer only, bit-exact with the reference's C# int semantics.
 //
 // Three kernel families live here:
-//   v3 "two-pass" (default for two-channel stream cfgs; last in the file): 8 packets per workgroup, channel A decoded
-//       for real in pass 0 (its end is where B starts: no pre-scan), parked, un-mixed with B in pass 1;
-//   v2 "split" (fallback of v3 for LPC orders above 8, default for one-channel cfgs): per workgroup one entropy wave
+//   v3 "two-pass" (default; last in the file): 8 packets per workgroup, channel A decoded for real in pass 0 (its end
+//       is where B starts: no pre-scan), parked, un-mixed with B in pass 1; one-channel packets finish in pass 0;
+//   v2 "split" (A/B reference; default only for one-channel cfgs in very big batches): per workgroup one entropy wave
 //       (pre-scan + Rice -> LDS residual queue) and reconstruction waves (FIR, un-mix, store), pipelined by one
 //       s_barrier per 16 samples;
 //   v1 "fused" (first, below): every lane group runs Rice and FIR itself.  Simplest correct form and A/B baseline.
@@ -960,15 +960,17 @@ __device__ __forceinline__ void split_kernel_body(const alac_decode_params& p) {
 
 
 // ===================================================================================================================
-// v3 "two-pass" kernel: 8 stereo packets per workgroup, three waves (entropy, output, FIR -- in that order, so that
-// consecutive workgroups placed round-robin on a CU's SIMDs never put two heavy waves on one SIMD).
+// v3 "two-pass" kernels: 8 packets per workgroup, three working waves (entropy, output, FIR; which wave takes which role
+// is decided from the SIMDs they landed on, see ab_kernel_body).
 // Pass 0 decodes channel A of all 8 packets for real (entropy wave -> residual queue -> P8 FIR wave) and the output
 // wave parks the reconstructed samples in the upper half of the packet's own output slot; where pass 0 ends IS where
 // channel B starts, so there is no Rice-only pre-scan any more.  Pass 1 decodes channel B the same way and the output
 // wave un-mixes it with the parked A samples (read back one chunk ahead) and stores the PCM.  Both passes keep every
 // lane of the FIR wave busy (8 streams x 8 taps), which the one-pass layout only manages with both channels at once.
-// One-channel and uncompressed packets finish in pass 0.  Only for workgroups whose streams all fit the P8 layout
-// (1 <= N <= 8); others are flagged for the fallback launch of a split kernel (alac_decode_params::ab_flags).
+// One-channel and uncompressed packets finish in pass 0.
+// alac_decode_ab_kernel takes the groups of 8 packets whose streams have LPC order 1..16 (one or two taps per lane of
+// the FIR wave) and flags the others (alac_decode_params::ab_flags) for alac_decode_ab32_kernel, launched behind it:
+// the same with two FIR waves in the 16-lanes-per-stream layout with two tap registers (any order, delta mode).
 // Parking place: ints [n, 2n) of the slot (slot_ints >= 2n for two channels).  The final stores of sample i touch
 // at most int 2i+1 (int32 output) or byte 6i+5 (packed), always below the parked samples not yet consumed.
 // ===================================================================================================================
