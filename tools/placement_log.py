@@ -1,3 +1,10 @@
+#!/usr/bin/env python3
+"""Where the waves of the two-pass kernel's workgroups ran.  Input: the per-workgroup stamps written with
+ALACGPU_DEBUG_STAMPS=1 ALACGPU_DEBUG_STAMPS_FILE=<file> (slots 3, 5, 6 = XCC_ID << 32 | HW_ID of waves 0, 1, 2 of each
+workgroup).  Prints, for the CUs that hold two workgroups, how far the second one's first wave sits from the first one's
+in the dispatcher's SIMD round (0, 2, 1, 3), and on how many CUs two heavy waves would share a SIMD if the roles went by
+wave index (entropy, output, FIR) -- the measurement behind the role assignment in ab_kernel_body ("Placement").
+usage: python tools/placement_log.py <file>"""
 import numpy as np, sys, collections
 a = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 8)
 a = a[a[:, 3] != 0]
