@@ -1401,9 +1401,13 @@ __device__ __forceinline__ int ab_finish24(const Meta& m, int val, int i, int ch
 
 // Ring refill service of the output wave (see AbShared): lane group r = lane >> 3 serves stream r, 16 bytes per lane.
 struct AbRefill {
-    static constexpr int ROUNDS = 2;           // up to 256 bytes per stream per chunk (a chunk of 32 samples consumes at most 236)
+    static constexpr int ROUNDS = AB_CHUNK / 16;   // up to 8 bytes per sample per stream per chunk (a sample consumes at most 59 bits)
     // a sample costs at most 59 bits (a run-length symbol, 9 + 16, and an escaped value, 9 + 25): never fall behind
     static_assert(AB_CHUNK * 59 <= ROUNDS * 128 * 8, "the ring refill must keep up with the worst-case consumption");
+    // what the entropy wave reads during a chunk was staged before the barrier that started it: the refill issued one barrier
+    // earlier left the ring >= RING_BYTES - 12 - 127 bytes ahead of the reader's position then, one chunk's consumption ago
+    static_assert(RING_BYTES - 12 - 127 - (AB_CHUNK * 59 + 7) / 8 >= (AB_CHUNK * 59 + 7) / 8 + 16,
+                  "a chunk this long can outrun a ring this small");
     const uint8_t* base;
     int64_t limit;
     AbShared& sh;
