@@ -71,9 +71,10 @@ int launch(alacgpu_ctx* ctx, const alac_decode_params& p_in, hipStream_t stream)
     // same stream.  The split kernels (variants 2..4: 2 / 4 / 8 packets per workgroup, twice that for one-channel cfgs)
     // remain as A/B references, and variant 4 as the choice for one-channel cfgs in very big batches.
     // One-channel cfgs finish in the two-pass kernel's first pass (8 packets per workgroup, no parking); measured on cfg4,
-    // two-pass / split: 1024 packets 0.44 / 0.51 ms, 4096 0.44 / 0.58, 8192 0.57 / 0.59, 16384 1.33 / 0.93 (more
-    // workgroups than fit at once: the 16-packet split workgroup wins), 32768 2.42 / 2.69.
-    if (variant == 0) variant = (ctx->all_mono && p.n_packets > 10240u) ? 4 : 5;
+    // two-pass / 16-packet split workgroups: 4096 packets 0.44 / 0.78 ms, 8192 0.57 / 0.81, 12288 0.98 / 0.87,
+    // 16384 1.20 / 0.93, 24576 1.60 / 1.91, 32768 2.07 / 2.65: the split kernel wins only where its 1024 workgroups
+    // all fit at once and the two-pass kernel's do not.
+    if (variant == 0) variant = (ctx->all_mono && p.n_packets > 10240u && p.n_packets <= 20480u) ? 4 : 5;
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
     if (variant == 5) {
         const size_t groups = ((size_t)p.n_packets + 7) / 8;

@@ -187,7 +187,7 @@ def main():
     if rank == 0:
         all_mono = all(c[5] == 1 for c in b["stream_cfgs"])
         split_auto = 4 if n_packets > (10240 if all_mono else 5120) else 3
-        auto = 4 if (all_mono and n_packets > 10240) else 5   # mirrors the library's choice (alacgpu_api.hip: launch)
+        auto = 4 if (all_mono and 10240 < n_packets <= 20480) else 5   # mirrors the library's choice (alacgpu_api.hip: launch)
         kernel_name = {1: "alac_decode_packets_kernel", 2: "alac_decode_split1_kernel", 3: "alac_decode_split2_kernel",
                        4: "alac_decode_split4_kernel", 5: "alac_decode_ab_kernel"}[args.variant or auto]
         if all_mono and (args.variant or auto) in (3, 4):

@@ -133,7 +133,7 @@ int alacgpu_set_output_format(alacgpu_ctx* ctx, int format);
 /* Tuning / A-B knob (no effect on results): 0 = auto (default), 1 = fused single-wave kernel,
  * 2 / 3 / 4 = split kernel with 1 / 2 / 4 reconstruction waves per workgroup, 5 = two-pass kernels (channel A, then
  * channel B: no Rice pre-scan; LPC orders up to 16, then everything else in a second launch).  Auto is 5, except 4 for
- * one-channel cfgs in batches above 10240 packets.  Also settable with
+ * one-channel cfgs in batches of 10241 to 20480 packets.  Also settable with
  * the environment variable ALACGPU_KERNEL_VARIANT at create time. */
 int alacgpu_set_kernel_variant(alacgpu_ctx* ctx, int variant);
 

@@ -222,9 +222,9 @@ def test_full_size_cfg2_roundtrip_property(pkg, synth):
 
 @pytest.mark.parametrize("stereo", [True, False])
 def test_auto_kernel_choice_above_the_big_batch_threshold(pkg, oracle, synth, stereo):
-    # above 10240 packets the library takes one-channel cfgs to the 16-packet split workgroups, and the two-pass kernels'
-    # fallback to the 8-packet ones above 5120: short packets keep the oracle fast; ragged sample counts and a last,
-    # partly filled workgroup included
+    # between 10241 and 20480 packets the library takes one-channel cfgs to the 16-packet split workgroups; two-channel cfgs
+    # stay with the two-pass kernels: short packets keep the oracle fast; ragged sample counts and a last, partly filled
+    # workgroup included
     count = 5203 if stereo else 10243
     d = synth.packet_descs(count, n=96, max_samples_per_frame=4096, stereo=int(stereo))
     rng = np.random.default_rng(count)
