@@ -38,6 +38,9 @@ assert CFG_DTYPE.itemsize == 12
 _VP = C.c_void_p
 SYMBOLS = {
     "alacgpu_version": (C.c_int, []),
+    "alacgpu_device_count": (C.c_int, []),
+    "alacgpu_alloc_pinned": (_VP, [C.c_size_t]),
+    "alacgpu_free_pinned": (None, [_VP]),
     "alacgpu_create": (C.c_int, [_VP, C.c_uint32, C.c_int, C.POINTER(_VP)]),
     "alacgpu_destroy": (None, [_VP]),
     "alacgpu_cfg_from_codec_data": (C.c_int, [_VP, C.c_uint32, C.c_int, C.c_int, _VP]),
@@ -48,7 +51,6 @@ SYMBOLS = {
     "alacgpu_expand_reference_layout": (C.c_size_t, [_VP, _VP, C.c_int32, _VP]),
     "alacgpu_format_samples": (C.c_size_t, [C.c_int, _VP, C.c_int32, _VP]),
     "alacgpu_last_kernel_ms": (C.c_float, [_VP]),
-    "alacgpu_set_kernel_variant": (C.c_int, [_VP, C.c_int]),
     "alacgpu_set_output_format": (C.c_int, [_VP, C.c_int]),
     "alacgpu_strerror": (C.c_char_p, [C.c_int]),
     "alacgpu_status_string": (C.c_char_p, [C.c_int]),
@@ -181,10 +183,6 @@ class AlacGpuContext:
         packet p's bytes are pcm[p].view(uint8)[:out_bytes[p]]."""
         _check(lib().alacgpu_set_output_format(self._ctx, fmt), self._ctx)
 
-    def set_kernel_variant(self, variant):
-        """0 auto, 1 fused kernel, 2/3/4 split kernel with 1/2/4 reconstruction waves, 5 two-pass kernel (results identical)."""
-        _check(lib().alacgpu_set_kernel_variant(self._ctx, variant), self._ctx)
-
     def last_kernel_ms(self):
         return float(lib().alacgpu_last_kernel_ms(self._ctx))
 
@@ -201,6 +199,44 @@ class AlacGpuContext:
                                         C.byref(st))
         _check(rc, self._ctx)
         return out, ob.value, st.value
+
+
+class PinnedBuffer:
+    """Page-locked host memory from alacgpu_alloc_pinned, viewed as a numpy array (batch buffers that are reused across
+    calls: transfers from and to it run at link speed).  Free with close() / as a context manager."""
+
+    def __init__(self, shape, dtype):
+        self._shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        self._dtype = np.dtype(dtype)
+        nbytes = int(np.prod(self._shape, dtype=np.int64)) * self._dtype.itemsize
+        self._p = lib().alacgpu_alloc_pinned(max(nbytes, 1))
+        if not self._p:
+            raise AlacGpuError("alacgpu_alloc_pinned failed")
+        buf = (C.c_uint8 * max(nbytes, 1)).from_address(self._p)
+        self.array = np.frombuffer(buf, dtype=self._dtype, count=int(np.prod(self._shape, dtype=np.int64))).reshape(self._shape)
+
+    def close(self):
+        if self._p:
+            self.array = None
+            lib().alacgpu_free_pinned(self._p)
+            self._p = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def device_count():
+    """Usable gfx950 devices (0: none -- creating a context then fails, there is no CPU fallback)."""
+    return int(lib().alacgpu_device_count())
 
 
 def expand_reference_layout(cfg_row, pcm, n_samples):

@@ -61,10 +61,33 @@ __device__ __forceinline__ int row_suffix_scan(int v) {
 }
 
 // ---- slow-path bit access straight from global memory (header, shift bytes, escape samples) ----
+// `limit` is the packet's readable byte count from `base` (Meta::limit): bytes at or past it read as ZERO, exactly like
+// the oracle's reader (and unlike the reference, which would see stale bytes of its reused 80 KiB buffer,
+// AlacContext.cs:64,195).  The device allocation is readable up to blob_bytes rounded up to 16, base is 16-byte aligned.
 __device__ __forceinline__ uint32_t load_be32(const uint8_t* base, int64_t byte_off, int64_t limit) {
     // byte_off is 4-aligned relative to a 16-aligned base
-    if (byte_off < 0 || byte_off + 4 > limit) return 0;
-    return __builtin_bswap32(*reinterpret_cast<const uint32_t*>(base + byte_off));
+    if (byte_off < 0 || byte_off >= limit) return 0;
+    uint32_t v = __builtin_bswap32(*reinterpret_cast<const uint32_t*>(base + byte_off));
+    const int64_t nv = limit - byte_off;                       // valid bytes in this dword when < 4
+    if (nv < 4) v &= ~(0xFFFFFFFFu >> (8 * (int)nv));
+    return v;
+}
+// 16 bytes at a 16-aligned offset, zero past `limit` (raw little-endian dwords, before the byte swap)
+__device__ __forceinline__ uint4 load16_clamped(const uint8_t* base, int64_t off, int64_t limit) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (off < limit) {
+        v = *reinterpret_cast<const uint4*>(base + off);
+        if (__builtin_expect(off + 16 > limit, 0)) {           // the packet ends inside these 16 bytes (once per stream)
+            const int nv = (int)(limit - off);                 // 1..15 valid bytes
+            uint32_t* w = reinterpret_cast<uint32_t*>(&v);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int nb = nv - 4 * i;
+                w[i] = nb >= 4 ? w[i] : (nb <= 0 ? 0u : (w[i] & ((1u << (8 * nb)) - 1u)));
+            }
+        }
+    }
+    return v;
 }
 // nbits in 1..32, MSB-first field starting at bit `bitpos`
 __device__ __forceinline__ uint32_t peek_bits(const uint8_t* base, int64_t limit, uint32_t bitpos, int nbits) {
@@ -420,8 +443,7 @@ __device__ __forceinline__ void ring_fill(uint32_t* ring, uint32_t& filled, uint
         if (!__builtin_amdgcn_ballot_w64(need)) break;
         if (need) {
             int64_t off = (int64_t)filled + l * 16;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (off + 16 <= limit) v = *reinterpret_cast<const uint4*>(base + off);
+            const uint4 v = load16_clamped(base, off, limit);
             uint4 o = make_uint4(__builtin_bswap32(v.x), __builtin_bswap32(v.y), __builtin_bswap32(v.z),
                                  __builtin_bswap32(v.w));
             *reinterpret_cast<uint4*>(&ring[(off & RING_MASK) >> 2]) = o;
@@ -430,50 +452,6 @@ __device__ __forceinline__ void ring_fill(uint32_t* ring, uint32_t& filled, uint
     }
 }
 
-// Refill with the global-load latency hidden: the loads for the next top-up are issued at the START of a
-// 16-sample chunk (the space they go to is already free then) and written to the ring at its END.
-// A chunk consumes at most ~118 bytes, so topping up by up to K x (LPS*16) >= 128 bytes per chunk keeps the ring
-// as full as ring_fill does.
-template <int LPS>
-struct RingPrefetch {
-    static constexpr int K = (128 + LPS * 16 - 1) / (LPS * 16);
-    uint4 v[K];
-    uint32_t cnt;
-};
-template <int LPS>
-__device__ __forceinline__ void ring_prefetch_issue(RingPrefetch<LPS>& pf, uint32_t filled, uint32_t next,
-                                                    const uint8_t* base, int64_t limit, int l, bool enable) {
-    constexpr uint32_t C = LPS * 16;
-    pf.cnt = 0;
-#pragma unroll
-    for (int k = 0; k < RingPrefetch<LPS>::K; k++) {
-        const bool need = enable && (filled + (uint32_t)(k + 1) * C <= (next - 12u) + RING_BYTES);
-        pf.v[k] = make_uint4(0, 0, 0, 0);
-        if (need) {
-            const int64_t off = (int64_t)filled + (int64_t)k * C + l * 16;
-            if (off + 16 <= limit) pf.v[k] = *reinterpret_cast<const uint4*>(base + off);
-            pf.cnt = (uint32_t)(k + 1);
-        }
-    }
-}
-template <int LPS>
-__device__ __forceinline__ void ring_prefetch_commit(const RingPrefetch<LPS>& pf, uint32_t* ring, uint32_t& filled, int l) {
-    constexpr uint32_t C = LPS * 16;
-#pragma unroll
-    for (int k = 0; k < RingPrefetch<LPS>::K; k++) {
-        if ((uint32_t)k < pf.cnt) {
-            const uint32_t off = filled + (uint32_t)k * C + (uint32_t)l * 16u;
-            uint4 v = pf.v[k];
-            // pin the byte swap HERE: hoisted up to the load (the compiler does that when it can) it would wait for the
-            // global load at the start of the chunk and expose the latency this prefetch exists to hide
-            asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
-            const uint4 o = make_uint4(__builtin_bswap32(v.x), __builtin_bswap32(v.y), __builtin_bswap32(v.z),
-                                       __builtin_bswap32(v.w));
-            *reinterpret_cast<uint4*>(&ring[(off & RING_MASK) >> 2]) = o;
-        }
-    }
-    filled += pf.cnt * C;
-}
 template <int LPS>
 __device__ __forceinline__ void rice_init(Rice& s, uint32_t& filled, uint32_t startbit, int init_hist, uint32_t* ring,
                                           const uint8_t* base, int64_t limit, int l, bool enable) {
@@ -569,20 +547,7 @@ __device__ __forceinline__ int fir_step(Fir<TPL>& f, int err, int i, int N, int 
     return out;
 }
 
-// ---- FIR fast step --------------------------------------------------------------------------------
-// The steady state of fir_step for one tap register per lane (1 <= N <= 16, i > N), branch-free.
-// Multiplies are the 32-bit v_mul_lo_u32: on gfx950 the 24-bit ones (v_mul_*24, v_mad_*24) issue at HALF its rate
-// (tools/ubench_issue.hip), so there is no narrow-operand variant; the clamp below covers every sample size.
-// NRED:   3 when every row of the wave has N <= 8 (taps live in lanes 0..7 only), else 4.
-// Lanes >= N keep coef == 0 and w == 0.  A row that is switched off is fed err = 0 / coef = 0 and just idles.
-struct FirLane {
-    int hist, coef, base;
-    int q, rnd, rss, qmask;   // row-uniform
-    uint32_t w;               // N - j for tap j < N, else 0
-    int bpaddr;               // ds_bpermute byte address of lane N-1 of this row
-    int tlo, thi;             // -1 / +1 on tap lanes (j < N), 0 / 0 elsewhere: bounds of the sign() median
-};
-
+// ---- DPP row reductions with a compile-time depth (NRED 3: taps in lanes 0..7 only) ------------------
 template <int NRED>
 __device__ __forceinline__ int row_allreduce_n(int v) {
     v = wadd(v, dpp0<DPP_QUAD_1032>(v));
@@ -598,28 +563,6 @@ __device__ __forceinline__ int row_suffix_scan_n(int v) {
     v = wadd(v, dpp0<DPP_ROW_SHL4>(v));
     if (NRED > 3) v = wadd(v, dpp0<DPP_ROW_SHL8>(v));
     return v;
-}
-
-template <int NRED>
-__device__ __forceinline__ void fir_fast(FirLane& f, int err) {
-    const int nb = __builtin_amdgcn_ds_bpermute(f.bpaddr, f.hist);   // tap N-1 = next step's base; needed last
-    const int d = wsub(f.hist, f.base);                                       // :303
-    const int p = wmul(d, f.coef);
-    const int sum = row_allreduce_n<NRED>(p);
-    const int out = __builtin_amdgcn_sbfe(wadd(wadd(wadd(f.rnd, sum) >> f.q, f.base), err), 0, f.rss);  // :306-310
-    // sign-LMS (:312-332), parallel form -- see fir_step for the derivation
-    const int s = err >> 31;
-    const int a = max(d, -d);
-    const uint32_t aq = (uint32_t)(a + (s & f.qmask)) >> f.q;
-    uint32_t cc = min(aq * f.w, 1u << 26);   // clamp: keeps the scan from wrapping, decisions unchanged
-    const uint32_t incl = (uint32_t)row_suffix_scan_n<NRED>((int)cc);
-    const uint32_t Ecc = (uint32_t)((err ^ s) - s) + cc;      // |err| + own decrement: visit iff |err| > incl - cc
-    // sign(d) for tap lanes, 0 elsewhere (tlo/thi are -1/+1 on tap lanes and 0/0 on the others)
-    int sd;
-    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(sd) : "v"(d), "v"(f.tlo), "v"(f.thi));
-    f.coef += (Ecc > incl) ? (sd ^ s) - s : 0;
-    f.hist = __builtin_amdgcn_update_dpp(out, f.hist, DPP_ROW_SHR1, 0xF, 0xF, false);
-    f.base = nb;
 }
 
 // ---- FIR fast step, two tap registers per lane ------------------------------------------------------
@@ -807,7 +750,7 @@ __device__ __forceinline__ void fir8x2_step(Fir8Lane2& f, int err, int i, bool a
 // Everything a lane knows about its packet / stream after the header parse.
 struct Meta {
     const uint8_t* base;   // 16-byte aligned-down packet start
-    int64_t limit;         // readable bytes from base
+    int64_t limit;         // readable bytes from base = up to the packet's last byte; what lies beyond reads as zero
     uint32_t size_bits_end; // bit position (from base) one past the packet's last bit
     int n;                 // samples per channel
     int status;
@@ -851,7 +794,9 @@ __device__ __forceinline__ Meta parse_meta(const alac_decode_params& p, uint32_t
         const uint32_t size = p.sizes[pkt];
         const uint32_t mis = (uint32_t)(off & 15u);
         m.base = p.blob + (off - mis);
-        m.limit = (int64_t)p.blob_limit - (int64_t)(off - mis);
+        // readable bytes from base: up to the packet's last byte (reads past it give zeros, as in the oracle), and never
+        // past the blob
+        m.limit = min((int64_t)p.blob_limit - (int64_t)(off - mis), (int64_t)mis + (int64_t)size);
         const uint32_t bit0 = mis * 8u;
         m.size_bits_end = bit0 + size * 8u;
         m.ss = cfg.sample_size;

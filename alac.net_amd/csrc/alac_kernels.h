@@ -39,10 +39,9 @@ struct alac_decode_params {
     int32_t* status;
     uint32_t out_format;        // 0: one int32 per sample; 1: packed little-endian PCM bytes (FormatSamples fused)
     unsigned long long* dbg;    // diagnostic builds only: per-workgroup s_memtime stamps (null in normal use)
-    // Two-pass kernels (alac_decode_ab_kernel, then alac_decode_ab32_kernel) and their fallback: flag g covers packets
-    // 8g .. 8g+7.  The first writes 0 where it decoded the group and 1 where it did not; the second looks at the groups
-    // flagged 1 and writes 2 where it decoded one; the split kernels, when handed the array, decode only the groups
-    // still flagged 1.  Null: no such protocol (a kernel does every packet).
+    // alac_decode_ab_kernel, then alac_decode_ab32_kernel: flag g covers packets 8g .. 8g+7.  The first writes 0 where it
+    // decoded the group and 1 where it did not; the second decodes the groups flagged 1 and writes 2 there.  One array per
+    // launch pair in flight (the host keeps a pool, alacgpu_api.hip: launch_slot).
     uint32_t* ab_flags;
     // Two-pass kernels: one counter per CU (index: XCC_ID, SE_ID, SH_ID, CU_ID), bumped by every workgroup that starts
     // there; its value, the workgroup's turn on the CU, rotates the roles of the workgroup's waves over the SIMDs.
@@ -51,18 +50,10 @@ struct alac_decode_params {
 };
 
 #ifdef __HIPCC__
-extern "C" __global__ void alac_decode_packets_kernel(alac_decode_params p);   // v1: fused, 2 packets / 64-thread WG
-extern "C" __global__ void alac_decode_split1_kernel(alac_decode_params p);    // v2: 1 entropy + 1 recon wave, 2 packets
-extern "C" __global__ void alac_decode_split2_kernel(alac_decode_params p);    // v2: 1 entropy + 2 recon waves, 4 packets
-extern "C" __global__ void alac_decode_ab_kernel(alac_decode_params p);        // v3: two passes (channel A, then B), 8 packets / 256-thread WG (three working waves), LPC orders 1..16
-extern "C" __global__ void alac_decode_ab32_kernel(alac_decode_params p);      // v3 for everything else (LPC orders 17..31, delta mode, order 0): two FIR waves (16-lane layout, 2 tap registers) / 256-thread WG
-extern "C" __global__ void alac_decode_split4_kernel(alac_decode_params p);    // v2: 1 entropy + 4 recon waves, 8 packets
-extern "C" __global__ void alac_decode_split2_mono_kernel(alac_decode_params p);  // one-channel streams: 8 packets / WG
-extern "C" __global__ void alac_decode_split4_mono_kernel(alac_decode_params p);  // one-channel streams: 16 packets / WG
+// two passes (channel A, then B), 8 packets / 256-thread workgroup (three working waves), LPC orders 1..16
+extern "C" __global__ void alac_decode_ab_kernel(alac_decode_params p);
+// the same for everything else (LPC orders 17..31, delta mode, order 0): two FIR waves (16-lane layout, 2 tap registers)
+extern "C" __global__ void alac_decode_ab32_kernel(alac_decode_params p);
 #endif
-
-// packets decoded per workgroup by alac_decode_packets_kernel
-#define ALAC_PACKETS_PER_WG 2
-#define ALAC_WG_THREADS 64
 
 #endif

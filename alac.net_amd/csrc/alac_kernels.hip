@@ -6,27 +6,12 @@
 // :256-336 = predictor_decompress_fir_adapt) and mid/side un-mixing + store (Deinterlace16/24
 // :338-421), integer only, bit-exact with the reference's C# int semantics.
 //
-// Three kernel families live here:
-//   v3 "two-pass" (default; last in the file): 8 packets per workgroup, channel A decoded for real in pass 0 (its end
-//       is where B starts: no pre-scan), parked, un-mixed with B in pass 1; one-channel packets finish in pass 0;
-//   v2 "split" (A/B reference; default only for one-channel cfgs in very big batches): per workgroup one entropy wave
-//       (pre-scan + Rice -> LDS residual queue) and reconstruction waves (FIR, un-mix, store), pipelined by one
-//       s_barrier per 16 samples;
-//   v1 "fused" (first, below): every lane group runs Rice and FIR itself.  Simplest correct form and A/B baseline.
-//
-// Mapping of v1, "fused row-per-stream":
-//   * one wave (64 lanes) = 4 rows of 16 lanes; a row owns one channel stream; a stereo packet is the
-//     row pair (A,B); a wave therefore decodes TWO packets (a workgroup is one wave).
-//   * the Rice state of a stream is replicated in its 16 lanes (row-uniform), so the residual is
-//     available to every tap lane with no broadcast; the bitstream is staged (byte-swapped to
-//     big-endian dwords) into a per-row LDS ring by coalesced 16-byte loads and read by a
-//     three-dword sliding window whose next dword is prefetched one step ahead.
-//   * the FIR keeps tap j's history sample and coefficient in lane j of the row (two registers per
-//     lane when 16 < N <= 30): history shifts with one DPP row_shr, the dot product is a 4-step DPP
-//     all-reduce, the sign-LMS early exit is a DPP suffix scan.
-//   * channel B's Rice stream starts where A's ends, so the A rows first run a Rice-only pre-scan to
-//     find that bit position; A and B are then decoded in lock step, un-mixed in registers every 16
-//     samples and stored as coalesced int32 PCM.
+// One kernel family lives here, the "two-pass" kernels: 8 packets per workgroup, channel A decoded
+// for real in pass 0 (its end is where B starts: no Rice-only pre-scan), parked in the packet's own output slot, and
+// un-mixed with B in pass 1; one-channel and uncompressed packets finish in pass 0.  Per workgroup: an entropy wave
+// (bitstream staged in per-stream LDS rings, branch-free speculative Rice units -> LDS residual queue), one or two FIR
+// waves (taps across lanes, DPP reductions and scans) and an output wave (un-mix, shift bytes, coalesced PCM stores, ring
+// refills).  (The round-1 "fused" and "split" families were retired in round 2; see git history and DESIGN.md.)
 // No MFMA: the path is integer/branchy, not a contraction.  No floating point anywhere.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -55,214 +40,9 @@ __device__ __forceinline__ void store_sample(const alac_decode_params& p, const 
     }
 }
 
-template <int TPL>
-__device__ void decode_wave(const alac_decode_params& p, const Meta& m, const alacgpu_cfg_dev& cfg, bool valid, int row, int l, int lane, int chan,
-                            uint32_t* ring, int32_t* pcm_slot, int32_t* st_out, uint32_t pkt) {
-    const bool compressed = valid && m.status == 0 && !m.esc;
-    const bool stream_on = compressed && (chan == 0 || m.stereo);
-    const int n_row = stream_on ? m.n : 0;
-    const int rowlane0 = lane & 48;
-    int flags = 0;
-
-    RiceCfg rc;
-    rc.kmod = cfg.rice_kmodifier;
-    rc.kmask = (1u << cfg.rice_kmodifier) - 1u;
-    rc.hist_mult = m.ricemod * (cfg.rice_history_mult / 4);  // :483,:643,:653
-    rc.rss = m.rss;
-
-    Rice rs;
-    rs.w0 = rs.w1 = rs.w2 = 0; rs.next = 12; rs.hist = 0; rs.signmod = 0; rs.zrun = 0; rs.nforce = 0;
-    const uint32_t ringa = lds_addr(ring);
-    rs.ra = rs.ra_sync = ringa;
-    rs.cur = rice_cursor(0, rs.ra);
-    uint32_t filled = 0;
-
-    // ---- pre-scan: Rice-only pass over channel A of stereo packets to find where B starts ----
-    const bool pre_on = stream_on && chan == 0 && m.stereo;
-    const int n_pre = pre_on ? m.n : 0;
-    int npre_max = max(max(__builtin_amdgcn_readlane(n_pre, 0), __builtin_amdgcn_readlane(n_pre, 16)),
-                       max(__builtin_amdgcn_readlane(n_pre, 32), __builtin_amdgcn_readlane(n_pre, 48)));
-    uint32_t bstart = m.ricebit;
-    if (npre_max > 0) {
-        rice_init<16>(rs, filled, m.ricebit, cfg.rice_initial_history, ring, m.base, m.limit, l, pre_on);
-        int dummy = 0;
-        for (int i = 0; i < npre_max; i++) {
-            if (i < n_pre) (void)rice_step(rs, rc, n_pre - 1 - i, i, &dummy, ringa);
-            if ((i & 15) == 15) {
-                wave_sync();
-                rice_sync(rs);
-                ring_fill<16>(ring, filled, rs.next, m.base, m.limit, l, pre_on);
-                wave_sync();
-            }
-        }
-        rice_sync(rs);
-        bstart = rice_bitpos(rs);
-    }
-    uint32_t other = (uint32_t)__shfl((int)bstart, lane ^ 16, 64);
-    const uint32_t startbit = (chan == 1) ? other : m.ricebit;
-
-    // ---- main pass ----
-    int nmax = max(max(__builtin_amdgcn_readlane(n_row, 0), __builtin_amdgcn_readlane(n_row, 16)),
-                   max(__builtin_amdgcn_readlane(n_row, 32), __builtin_amdgcn_readlane(n_row, 48)));
-    // escape packets have no Rice/FIR work but still need the output stage
-    const int n_out = (valid && m.status == 0) ? m.n : 0;
-    int nout_max = max(max(__builtin_amdgcn_readlane(n_out, 0), __builtin_amdgcn_readlane(n_out, 16)),
-                       max(__builtin_amdgcn_readlane(n_out, 32), __builtin_amdgcn_readlane(n_out, 48)));
-    if (nmax > 0) rice_init<16>(rs, filled, startbit, cfg.rice_initial_history, ring, m.base, m.limit, l, stream_on);
-
-    Fir<TPL> f;
-#pragma unroll
-    for (int t = 0; t < TPL; t++) {
-        int j = l + 16 * t;
-        f.hist[t] = 0;
-        int cv = 0;
-        if (stream_on && j < m.N) cv = (int)(int16_t)peek_bits(m.base, m.limit, m.coefbit + 16u * j, 16);  // :468-474
-        f.coef[t] = cv;
-    }
-    f.base = 0;
-    f.prev = 0;
-
-    int cap = 0;
-    for (int i0 = 0; i0 < nout_max; i0 += 16) {
-        if (i0 < nmax) {
-            int iend = min(16, nmax - i0);
-            for (int ii = 0; ii < iend; ii++) {
-                int i = i0 + ii;
-                if (i < n_row) {
-                    int err = rice_step(rs, rc, n_row - 1 - i, i, &flags, ringa);
-                    int out = fir_step<TPL>(f, err, i, m.N, m.q, m.rnd, m.rss, l, rowlane0);
-                    cap = (l == ii) ? out : cap;
-                }
-            }
-            wave_sync();
-            rice_sync(rs);
-            ring_fill<16>(ring, filled, rs.next, m.base, m.limit, l, stream_on && i0 + 16 < n_row);
-            wave_sync();
-        }
-        // ---- output stage: 16 sample frames per packet, un-mix + shift bytes + coalesced store ----
-        int i = i0 + l;
-        bool live = i < n_out;
-        int mine = cap;
-        if (live && m.esc && (chan == 0 || m.stereo)) {  // raw samples (:500-525 / :665-699)
-            uint32_t bp = m.rawbit + (uint32_t)((i * (m.stereo ? 2 : 1) + chan) * m.ss);
-            int v = (int)peek_bits(m.base, m.limit, bp, m.ss);
-            mine = __builtin_amdgcn_sbfe(v, 0, m.ss);
-        }
-        int partner = __shfl(mine, lane ^ 16, 64);
-        if (live) {
-            int a = chan == 0 ? mine : partner, b = chan == 0 ? partner : mine;
-            int val;
-            if (m.stereo) {
-                int left, right;
-                if (m.mixweight != 0) {                                 // :344-351
-                    right = wsub(a, wmul(b, m.mixweight) >> (m.mixshift & 31));
-                    left = wadd(right, b);
-                } else {
-                    left = a;
-                    right = b;
-                }
-                val = chan == 0 ? left : right;
-            } else {
-                val = chan == 0 ? a : 0;                                 // :531-541: silent second channel
-            }
-            if (m.ss == 24) {
-                if (m.ub != 0 && !m.esc && (chan == 0 || m.stereo)) {   // :381-388 / :549-554
-                    uint32_t bp = m.ubit + (uint32_t)((i * (m.stereo ? 2 : 1) + chan) * 8 * m.ub);
-                    uint32_t sb = peek_bits(m.base, m.limit, bp, 8 * m.ub);
-                    val = (int)(((uint32_t)val << (8 * m.ub)) | sb);
-                }
-                val = __builtin_amdgcn_sbfe(val, 0, 24);
-            }
-            if (chan < m.nc) store_sample(p, m, pcm_slot, (int64_t)i * m.nc + chan, val);
-        }
-    }
-
-    // ---- status: same priority order as the oracle / the reference's control flow ----
-    rice_sync(rs);
-    int fl_other = __shfl(flags, lane ^ 16, 64);
-    int pt_other = __shfl(m.predtype, lane ^ 16, 64);
-    int N_other = __shfl(m.N, lane ^ 16, 64);
-    uint32_t endbit = rice_bitpos(rs);
-    uint32_t end_other = (uint32_t)__shfl((int)endbit, lane ^ 16, 64);
-    if (valid && l == 0 && chan == 0) {
-        int st = m.status;
-        if (st == 0 && !m.esc) {
-            const int nch = m.stereo ? 2 : 1;
-            for (int c = 0; c < nch && st == 0; c++) {
-                int fl = c == 0 ? flags : fl_other;
-                int pt = c == 0 ? m.predtype : pt_other;
-                int Nc = c == 0 ? m.N : N_other;
-                if (fl & 1) st = ALACGPU_ST_OVERRUN_D;
-                else if (fl & 2) st = ALACGPU_ST_UNSUPPORTED_PARAMS_D;
-                else if (pt != 0) st = ALACGPU_ST_UNSUPPORTED_PREDTYPE_D;
-                else if (Nc == 0 && m.n > 4096) st = ALACGPU_ST_REF_THROWS_D;
-            }
-            uint32_t last = m.stereo ? end_other : endbit;
-            if (st == 0 && last > m.size_bits_end) st = ALACGPU_ST_OVERRUN_D;
-        } else if (st == 0 && m.esc) {
-            uint32_t last = m.rawbit + (uint32_t)(m.n * (m.stereo ? 2 : 1) * m.ss);
-            if (last > m.size_bits_end) st = ALACGPU_ST_OVERRUN_D;
-        }
-        st_out[pkt] = st;
-    }
-}
-
-}  // namespace
-
-extern "C" __global__ __launch_bounds__(64) void alac_decode_packets_kernel(alac_decode_params p) {
-    __shared__ __attribute__((aligned(1024))) uint32_t ring_all[4][RING_BYTES / 4];
-    const int lane = threadIdx.x;
-    const int row = lane >> 4, l = lane & 15, chan = row & 1;
-    const uint32_t pkt = blockIdx.x * 2u + (uint32_t)(row >> 1);
-    const bool valid = pkt < p.n_packets;
-
-    alacgpu_cfg_dev cfg;
-    Meta m = parse_meta(p, pkt, chan, valid, cfg);
-    if (valid && l == 0 && chan == 0) {
-        if (p.out_bytes) p.out_bytes[pkt] = m.out_bytes;
-        if (p.out_samples) p.out_samples[pkt] = m.n;
-    }
-
-    int32_t* pcm_slot = p.pcm_out + (int64_t)pkt * p.slot_ints;
-    uint32_t* ring = ring_all[row];
-    // two tap registers per lane only when some stream in this wave needs more than 16 taps
-    const bool wide = valid && m.status == 0 && !m.esc && m.N > 16 && m.N <= 30 && (chan == 0 || m.stereo);
-    if (__builtin_amdgcn_ballot_w64(wide))
-        decode_wave<2>(p, m, cfg, valid, row, l, lane, chan, ring, pcm_slot, p.status, pkt);
-    else
-        decode_wave<1>(p, m, cfg, valid, row, l, lane, chan, ring, pcm_slot, p.status, pkt);
-}
-
-// =====================================================================================================
-// v2 "split" kernel: one workgroup = 1 entropy wave + F reconstruction waves, 2F packets.
-//
-//   entropy wave      groups of 64/(4F) lanes, one group per channel stream (4F streams).  Runs the
-//                     Rice-only pre-scan of the A streams, then decodes every stream in lock step and
-//                     writes one residual per stream per step into an LDS queue (double-buffered chunks
-//                     of 16 steps).  It also keeps the per-stream bitstream rings topped up.
-//   reconstruction    each wave owns 2 packets = 4 streams = 4 rows of 16 lanes (tap j in lane j): reads
-//   waves             the residual (LDS broadcast), runs the adaptive FIR, and every 16 steps un-mixes the
-//                     last 16 outputs -- which are sitting in the history register, lane j = out[i-j] --
-//                     and stores them as coalesced int32 PCM.
-//   One s_barrier per 16-step chunk hands a chunk over; the per-step instruction stream of each wave is
-//   roughly half of the fused kernel's, which is what bounds a dependent integer chain on CDNA4
-//   (one wave issues ~1 instruction per 5-8 cycles; see profiles/r1_ubench_issue_rates.txt).
-// =====================================================================================================
-namespace {
-
-constexpr int CHUNK = 16;
 #ifndef ALAC_ENTROPY_PRIO
 #define ALAC_ENTROPY_PRIO 3
 #endif
-
-template <int F>
-struct SplitShared {
-    uint32_t rings[4 * F][RING_BYTES / 4];
-    int resq[2][CHUNK][4 * F];
-    int zeros[CHUNK][4 * F];   // residuals of a switched-off row
-    int outq[2][2][F >= 2 ? F / 2 : 1][64];   // P8 layout: FIR wave -> output wave, 8 outputs per stream per half chunk
-    int dummy[CHUNK * 4 * F + 64];
-};
 
 template <typename T>
 __device__ __forceinline__ T wave_max(T v) {
@@ -387,577 +167,6 @@ __device__ __forceinline__ bool spec_unit(Rice& rs, int& full_left, const RiceCf
 
 // value of `v` in lane `src` (a lane mirrors itself when src == its own id)
 __device__ __forceinline__ int mirror_i(int v, int src) { return __shfl(v, src, 64); }
-
-// MONO (every stream cfg of the context has one channel): a stream IS a packet -- no B channel, no
-// pre-scan, twice as many packets per workgroup.
-template <bool MONO> __device__ __forceinline__ int stream_packet(int g) { return MONO ? g : (g >> 1); }
-template <bool MONO> __device__ __forceinline__ int stream_chan(int g) { return MONO ? 0 : (g & 1); }
-
-template <int F, bool MONO>
-__device__ void entropy_wave(const alac_decode_params& p, uint32_t pkt0, int lane, SplitShared<F>& sh, int nchunks) {
-    constexpr int S = 4 * F, LPS = 64 / S;
-    const int g = lane / LPS, sub = lane % LPS;
-    const int chan = stream_chan<MONO>(g);
-    const uint32_t pkt = pkt0 + (uint32_t)stream_packet<MONO>(g);
-    const bool valid = pkt < p.n_packets;
-    alacgpu_cfg_dev cfg;
-    const Meta m = parse_meta(p, pkt, chan, valid, cfg);
-    if (valid && sub == 0 && chan == 0) {
-        if (p.out_bytes) p.out_bytes[pkt] = m.out_bytes;
-        if (p.out_samples) p.out_samples[pkt] = m.n;
-    }
-    const bool compressed = valid && m.status == 0 && !m.esc;
-    const bool stream_on = compressed && (chan == 0 || m.stereo);
-    const int n_row = stream_on ? m.n : 0;
-    int flags = 0;
-
-    RiceCfg rc;
-    rc.kmod = cfg.rice_kmodifier;
-    rc.kmask = (1u << cfg.rice_kmodifier) - 1u;
-    rc.hist_mult = m.ricemod * (cfg.rice_history_mult / 4);
-    rc.rss = m.rss;
-    int init_hist = cfg.rice_initial_history;
-
-    int full_left = 0;   // > 0: stay on the escape-capable speculative tier (see spec_unit)
-    Rice rs;
-    rs.w0 = rs.w1 = rs.w2 = 0; rs.next = 12; rs.hist = 0; rs.signmod = 0; rs.zrun = 0; rs.nforce = 0;
-    rs.ra = rs.ra_sync = lds_addr(sh.rings[g]);
-    rs.cur = rice_cursor(0, rs.ra);
-    uint32_t filled = 0;
-    if (p.dbg && lane == 0) {
-        p.dbg[8 * blockIdx.x + 0] = clock64();
-        const unsigned hw = __builtin_amdgcn_s_getreg(63492), xcc = __builtin_amdgcn_s_getreg(63508);
-        p.dbg[8 * blockIdx.x + 3] = ((unsigned long long)xcc << 32) | hw;   // placement (HW_ID, XCC_ID)
-    }
-
-    // ---- pre-scan: Rice-only pass over the A stream of every stereo packet, to find where B starts ----
-    // Lanes with nothing to scan shadow the first scanning group (same ring, same state), so the whole
-    // wave stays in lock step on the branch-free fast step.
-    const bool pre_on = stream_on && chan == 0 && m.stereo;
-    uint32_t bstart = m.ricebit;
-    {
-        const uint64_t onmask = __builtin_amdgcn_ballot_w64(pre_on);
-        if (onmask) {
-            const int src = pre_on ? lane : (int)__builtin_ctzll(onmask);
-            RiceCfg pc;
-            pc.kmod = mirror_i(rc.kmod, src);
-            pc.kmask = (1u << pc.kmod) - 1u;
-            pc.hist_mult = mirror_i(rc.hist_mult, src);
-            pc.rss = mirror_i(rc.rss, src);
-            const int n_eff = mirror_i(m.n, src);
-            const int ih = mirror_i(init_hist, src);
-            const uint32_t sb = (uint32_t)mirror_i((int)m.ricebit, src);
-            const uint32_t* pringp = sh.rings[mirror_i(g, src)];
-            const uint32_t pring = lds_addr(pringp);
-            const int nmin = __builtin_amdgcn_readfirstlane(-wave_max(-n_eff));
-            const int nmax = __builtin_amdgcn_readfirstlane(wave_max(pre_on ? m.n : 0));
-            rice_init<LPS>(rs, filled, sb, ih, sh.rings[g], m.base, m.limit, sub, pre_on);
-            // the shadows read the donor's ring: reload their window from it
-            if (!pre_on) {
-                const uint32_t d0 = rs.next - 12u;
-                rs.w0 = pringp[(d0 & RING_MASK) >> 2];
-                rs.w1 = pringp[((d0 + 4u) & RING_MASK) >> 2];
-                rs.w2 = pringp[((d0 + 8u) & RING_MASK) >> 2];
-                rs.cur = rice_cursor((int)(rs.cur & 31u), pring | ((d0 + 8u) & RING_MASK));
-                rs.ra = rs.ra_sync = pring | ((d0 + 8u) & RING_MASK);
-            }
-            int dummy = 0;
-            int i = 0;
-            for (; i + CHUNK <= nmin - 1; i += CHUNK) {   // every lane has a sample left after each of these
-                RingPrefetch<LPS> pf;
-                ring_prefetch_issue<LPS>(pf, filled, rs.next, m.base, m.limit, sub, pre_on);
-                for (int u = 0; u < CHUNK; u += SPEC_UNIT) {
-                    const bool redo = !spec_unit<false, 0>(rs, full_left, pc, pring, nullptr);
-                    if (redo) {
-                        for (int ii = 0; ii < SPEC_UNIT; ii++)
-                            (void)rice_step(rs, pc, n_eff - 1 - (i + u + ii), i + u + ii, &dummy, pring);
-                    }
-                }
-                wave_sync();
-                rice_sync(rs);
-                ring_prefetch_commit<LPS>(pf, sh.rings[g], filled, sub);
-                wave_sync();
-            }
-            for (; i < nmax; i++) {                        // ragged tail, generic
-                if (pre_on && i < m.n) (void)rice_step(rs, pc, m.n - 1 - i, i, &dummy, pring);
-                if ((i & 15) == 15) {
-                    wave_sync();
-                    rice_sync(rs);
-                    ring_fill<LPS>(sh.rings[g], filled, rs.next, m.base, m.limit, sub, pre_on && i + 1 < m.n);
-                    wave_sync();
-                }
-            }
-            rice_sync(rs);
-            bstart = rice_bitpos(rs);
-        }
-    }
-    const uint32_t other = (uint32_t)__shfl((int)bstart, lane ^ LPS, 64);
-    const uint32_t startbit = (chan == 1) ? other : m.ricebit;
-    if (p.dbg && lane == 0) p.dbg[8 * blockIdx.x + 1] = clock64();
-
-    // ---- main pass: every stream, one residual per step into the LDS queue ----
-    const uint64_t onmask = __builtin_amdgcn_ballot_w64(stream_on);
-    const int src = (stream_on || !onmask) ? lane : (int)__builtin_ctzll(onmask);
-    RiceCfg mc;
-    mc.kmod = mirror_i(rc.kmod, src);
-    mc.kmask = (1u << mc.kmod) - 1u;
-    mc.hist_mult = mirror_i(rc.hist_mult, src);
-    mc.rss = mirror_i(rc.rss, src);
-    const int n_eff = mirror_i(m.n, src);
-    const int ih = mirror_i(init_hist, src);
-    const uint32_t sb = (uint32_t)mirror_i((int)startbit, src);
-    const uint32_t* mringp = sh.rings[mirror_i(g, src)];
-    const uint32_t mring = lds_addr(mringp);
-    const int nmin = onmask ? __builtin_amdgcn_readfirstlane(-wave_max(-n_eff)) : 0;
-    const int nmax = __builtin_amdgcn_readfirstlane(wave_max(n_row));
-    if (nmax > 0) {
-        rice_init<LPS>(rs, filled, sb, ih, sh.rings[g], m.base, m.limit, sub, stream_on);
-        if (!stream_on) {
-            const uint32_t d0 = rs.next - 12u;
-            rs.w0 = mringp[(d0 & RING_MASK) >> 2];
-            rs.w1 = mringp[((d0 + 4u) & RING_MASK) >> 2];
-            rs.w2 = mringp[((d0 + 8u) & RING_MASK) >> 2];
-            rs.cur = rice_cursor((int)(rs.cur & 31u), mring | ((d0 + 8u) & RING_MASK));
-            rs.ra = rs.ra_sync = mring | ((d0 + 8u) & RING_MASK);
-        }
-    }
-
-    unsigned long long ewait = 0;
-    int nredo = 0;
-    for (int c = 0; c < nchunks; c++) {
-        const int i0 = c * CHUNK;
-        // residual queue slot of this stream; lanes other than the group's first write to a dummy word
-        int* q = (sub == 0) ? &sh.resq[c & 1][0][g] : &sh.dummy[lane];
-        if (i0 < nmax) {
-            const bool fast_chunk = i0 + CHUNK <= nmin - 1;   // all lanes decode, a sample always remains
-            RingPrefetch<LPS> pf;
-            pf.cnt = 0;
-            if (fast_chunk) {
-                ring_prefetch_issue<LPS>(pf, filled, rs.next, m.base, m.limit, sub, stream_on && i0 + CHUNK < n_row);
-                for (int u = 0; u < CHUNK; u += SPEC_UNIT) {
-                    const bool redo = !spec_unit<true, S>(rs, full_left, mc, mring, q + u * S);
-                    if (redo) nredo++;
-                    if (redo) {   // some lane met an escape / a zero run: decode this unit with the full step
-                        for (int ii = 0; ii < SPEC_UNIT; ii++)
-                            q[(u + ii) * S] = rice_step(rs, mc, n_eff - 1 - (i0 + u + ii), i0 + u + ii, &flags, mring);
-                    }
-                }
-            } else {                                        // generic chunk (ragged sample counts, last samples)
-                const int qstride = (sub == 0) ? S : 0;
-                for (int ii = 0; ii < CHUNK; ii++) {
-                    const int i = i0 + ii;
-                    int r = 0;
-                    if (i < n_row) r = rice_step(rs, mc, n_row - 1 - i, i, &flags, mring);
-                    q[ii * qstride] = r;
-                }
-            }
-            wave_sync();
-            rice_sync(rs);
-            if (fast_chunk) ring_prefetch_commit<LPS>(pf, sh.rings[g], filled, sub);
-            else ring_fill<LPS>(sh.rings[g], filled, rs.next, m.base, m.limit, sub, stream_on && i0 + CHUNK < n_row);
-        }
-        const unsigned long long tb = p.dbg ? clock64() : 0;
-        wg_sync();  // chunk c is ready for the reconstruction waves
-        if (p.dbg) ewait += clock64() - tb;
-    }
-    wg_sync();      // final barrier (every wave of the workgroup executes nchunks + 1): P8 FIR wave -> output wave
-    if (p.dbg && lane == 0) {
-        p.dbg[8 * blockIdx.x + 5] = p.dbg[8 * blockIdx.x + 0] + ewait;
-        p.dbg[8 * blockIdx.x + 7] = p.dbg[8 * blockIdx.x + 0] + (unsigned long long)nredo;
-    }
-    if (!stream_on) flags = 0;  // shadows decode somebody else's stream
-    if (p.dbg && lane == 0) p.dbg[8 * blockIdx.x + 2] = clock64();
-
-    // ---- status, in the reference's control-flow order (same as v1 / the oracle) ----
-    rice_sync(rs);
-    const int fl_other = __shfl(flags, lane ^ LPS, 64);
-    const int pt_other = __shfl(m.predtype, lane ^ LPS, 64);
-    const int N_other = __shfl(m.N, lane ^ LPS, 64);
-    const uint32_t endbit = rice_bitpos(rs);
-    const uint32_t end_other = (uint32_t)__shfl((int)endbit, lane ^ LPS, 64);
-    if (valid && sub == 0 && chan == 0) {
-        int st = m.status;
-        if (st == 0 && !m.esc) {
-            const int nch = m.stereo ? 2 : 1;
-            for (int c = 0; c < nch && st == 0; c++) {
-                const int fl = c == 0 ? flags : fl_other;
-                const int pt = c == 0 ? m.predtype : pt_other;
-                const int Nc = c == 0 ? m.N : N_other;
-                if (fl & 1) st = ALACGPU_ST_OVERRUN_D;
-                else if (fl & 2) st = ALACGPU_ST_UNSUPPORTED_PARAMS_D;
-                else if (pt != 0) st = ALACGPU_ST_UNSUPPORTED_PREDTYPE_D;
-                else if (Nc == 0 && m.n > 4096) st = ALACGPU_ST_REF_THROWS_D;
-            }
-            const uint32_t last = m.stereo ? end_other : endbit;
-            if (st == 0 && last > m.size_bits_end) st = ALACGPU_ST_OVERRUN_D;
-        } else if (st == 0 && m.esc) {
-            const uint32_t last = m.rawbit + (uint32_t)(m.n * (m.stereo ? 2 : 1) * m.ss);
-            if (last > m.size_bits_end) st = ALACGPU_ST_OVERRUN_D;
-        }
-        p.status[pkt] = st;
-    }
-}
-
-// Output stage of a reconstruction wave: un-mix + shift bytes + coalesced int32 store of the (up to) 16
-// sample frames of chunk i0.  `newest` is hist[0]: lane j holds out[last - j].
-__device__ __forceinline__ void recon_output(const alac_decode_params& p, const Meta& m, int newest, int i0, int n_out,
-                                             int lane, int chan, int32_t* pcm_slot) {
-    const int l = lane & 15;
-    const int cnt = min(CHUNK, n_out - i0);   // frames of this packet in this chunk (<= 0: none)
-    const bool live = l < cnt;
-    const int i = m.esc ? i0 + l : i0 + cnt - 1 - l;
-    int mine = newest;
-    if (live && m.esc && (chan == 0 || m.stereo)) {  // raw samples (:500-525 / :665-699)
-        const uint32_t bp = m.rawbit + (uint32_t)((i * (m.stereo ? 2 : 1) + chan) * m.ss);
-        mine = __builtin_amdgcn_sbfe((int)peek_bits(m.base, m.limit, bp, m.ss), 0, m.ss);
-    }
-    const int partner = __shfl(mine, lane ^ 16, 64);
-    if (live) {
-        const int a = chan == 0 ? mine : partner, b = chan == 0 ? partner : mine;
-        int val;
-        if (m.stereo) {
-            int left, right;
-            if (m.mixweight != 0) {                                     // :344-351
-                right = wsub(a, wmul(b, m.mixweight) >> (m.mixshift & 31));
-                left = wadd(right, b);
-            } else {
-                left = a;
-                right = b;
-            }
-            val = chan == 0 ? left : right;
-        } else {
-            val = chan == 0 ? a : 0;                                     // :531-541: silent second channel
-        }
-        if (m.ss == 24) {
-            if (m.ub != 0 && !m.esc && (chan == 0 || m.stereo)) {       // :381-388 / :549-554
-                const uint32_t bp = m.ubit + (uint32_t)((i * (m.stereo ? 2 : 1) + chan) * 8 * m.ub);
-                const uint32_t sb = peek_bits(m.base, m.limit, bp, 8 * m.ub);
-                val = (int)(((uint32_t)val << (8 * m.ub)) | sb);
-            }
-            val = __builtin_amdgcn_sbfe(val, 0, 24);
-        }
-        if (chan < m.nc) store_sample(p, m, pcm_slot, (int64_t)i * m.nc + chan, val);
-    }
-}
-
-template <int F, int TPL>
-__device__ void recon_wave_impl(const alac_decode_params& p, const Meta& m, bool valid, int g, int chan, int lane,
-                                SplitShared<F>& sh, int nchunks, uint32_t pkt) {
-    constexpr int S = 4 * F;
-    const int l = lane & 15;
-    const int rowlane0 = lane & 48;
-    const bool compressed = valid && m.status == 0 && !m.esc;
-    const bool stream_on = compressed && (chan == 0 || m.stereo);
-    const int n_row = stream_on ? m.n : 0;
-    const int n_out = (valid && m.status == 0) ? m.n : 0;
-    int32_t* pcm_slot = p.pcm_out + (int64_t)pkt * p.slot_ints;
-
-    Fir<TPL> f;
-#pragma unroll
-    for (int t = 0; t < TPL; t++) {
-        const int j = l + 16 * t;
-        f.hist[t] = 0;
-        int cv = 0;
-        if (stream_on && j < m.N) cv = (int)(int16_t)peek_bits(m.base, m.limit, m.coefbit + 16u * j, 16);
-        f.coef[t] = cv;
-    }
-    f.base = 0;
-    f.prev = 0;
-    const int nmax = __builtin_amdgcn_readfirstlane(wave_max(n_row));
-
-    // ---- fast-path eligibility (wave-uniform) ----
-    // every switched-on row in the general predictor mode with one tap register: 1 <= N <= 16
-    const bool row_ok = !stream_on || (m.N >= 1 && m.N <= 16);
-    const bool can_fast = TPL == 1 && !__builtin_amdgcn_ballot_w64(!row_ok) && nmax > 0;
-    const int Nw = __builtin_amdgcn_readfirstlane(wave_max(stream_on ? m.N : 0));
-    const int nmin = __builtin_amdgcn_readfirstlane(-wave_max(stream_on ? -m.n : -0x7FFFFFFF));
-
-    FirLane fl;
-    fl.q = stream_on ? m.q : 1;
-    fl.rnd = stream_on ? m.rnd : 0;
-    fl.rss = stream_on ? m.rss : 16;
-    fl.qmask = (1 << fl.q) - 1;
-    const bool tap = stream_on && l < m.N;
-    fl.tlo = tap ? -1 : 0;
-    fl.thi = tap ? 1 : 0;
-    fl.w = tap ? (uint32_t)(m.N - l) : 0u;
-    fl.bpaddr = (rowlane0 + (stream_on ? (m.N - 1) & 15 : 0)) * 4;
-    const int* qzero = &sh.zeros[0][g];
-
-    // ---- two-register fast path (some stream of the wave has more than 16 taps, or is in delta mode) ----
-    const bool row_ok2 = !stream_on || m.N >= 1;
-    const bool can_fast2 = TPL == 2 && !__builtin_amdgcn_ballot_w64(!row_ok2) && nmax > 0;
-    const int Nw2 = __builtin_amdgcn_readfirstlane(wave_max((stream_on && m.N != 31) ? m.N : 0));
-    FirLane2 f2;
-    f2.q = fl.q; f2.rnd = fl.rnd; f2.rss = fl.rss; f2.qmask = fl.qmask;
-    f2.delta = stream_on && m.N == 31;
-#pragma unroll
-    for (int t = 0; t < 2; t++) {
-        const int j = l + 16 * t;
-        const bool tp = stream_on && m.N != 31 && j < m.N;
-        f2.tlo[t] = tp ? -1 : 0;
-        f2.thi[t] = tp ? 1 : 0;
-        f2.w[t] = tp ? (uint32_t)(m.N - j) : 0u;
-    }
-    f2.bphi = stream_on && m.N != 31 && m.N > 16;
-    f2.bpaddr = (rowlane0 + ((stream_on && m.N != 31) ? (m.N - 1) & 15 : 0)) * 4;
-
-    unsigned long long rwait = 0;
-    for (int c = 0; c < nchunks; c++) {
-        const int i0 = c * CHUNK;
-        const unsigned long long tb = (p.dbg && c > 0) ? clock64() : 0;
-        wg_sync();  // wait for chunk c
-        if (p.dbg && c > 0) rwait += clock64() - tb;
-        if (p.dbg && c == 0 && lane == 0 && g == 0) p.dbg[8 * blockIdx.x + 3] = clock64();
-        if (i0 < nmax) {
-            const int* q = &sh.resq[c & 1][0][g];
-            if (TPL == 1 && can_fast && i0 > Nw && i0 + CHUNK <= nmin) {
-                fl.hist = f.hist[0];
-                fl.coef = f.coef[0];
-                fl.base = f.base;
-                const int* qf = stream_on ? q : qzero;
-                int err = qf[0];
-#define ALAC_FAST_CHUNK(NRED_)                                            \
-    _Pragma("unroll") for (int ii = 0; ii < CHUNK; ii++) {                \
-        const int en = qf[(ii + 1 < CHUNK ? ii + 1 : ii) * S];            \
-        fir_fast<NRED_>(fl, err);                                         \
-        err = en;                                                         \
-    }
-                if (Nw <= 8) { ALAC_FAST_CHUNK(3) } else { ALAC_FAST_CHUNK(4) }
-#undef ALAC_FAST_CHUNK
-                f.hist[0] = fl.hist;
-                f.coef[0] = fl.coef;
-                f.base = fl.base;
-                f.prev = __shfl(fl.hist, rowlane0, 64);
-            } else if (TPL == 2 && can_fast2 && i0 > Nw2 && i0 + CHUNK <= nmin) {
-                f2.hist[0] = f.hist[0];
-                f2.hist[1] = f.hist[TPL - 1];
-                f2.coef[0] = f.coef[0];
-                f2.coef[1] = f.coef[TPL - 1];
-                f2.base = f.base;
-                f2.prev = f.prev;
-                const int* qf = stream_on ? q : qzero;
-                int err = qf[0];
-#pragma unroll
-                for (int ii = 0; ii < CHUNK; ii++) {
-                    const int en = qf[(ii + 1 < CHUNK ? ii + 1 : ii) * S];
-                    fir_fast2(f2, err);
-                    err = en;
-                }
-                f.hist[0] = f2.hist[0];
-                f.hist[TPL - 1] = f2.hist[1];
-                f.coef[0] = f2.coef[0];
-                f.coef[TPL - 1] = f2.coef[1];
-                f.base = f2.base;
-                f.prev = f2.prev;
-            } else {
-                for (int ii = 0; ii < CHUNK; ii++) {
-                    const int i = i0 + ii;
-                    if (i < n_row) {
-                        const int err = q[ii * S];
-                        (void)fir_step<TPL>(f, err, i, m.N, m.q, m.rnd, m.rss, l, rowlane0);
-                    }
-                }
-            }
-        }
-        recon_output(p, m, f.hist[0], i0, n_out, lane, chan, pcm_slot);
-    }
-    wg_sync();      // final barrier, see entropy_wave
-    if (p.dbg && lane == 0 && g == 0) {
-        p.dbg[8 * blockIdx.x + 4] = clock64();
-        p.dbg[8 * blockIdx.x + 6] = p.dbg[8 * blockIdx.x + 0] + rwait;
-    }
-}
-
-// Output stage of the P8 layout for the 8 sample frames starting at ih: lane (2t + par) of a row holds
-// out[last - t] of its stream; the A/B partner of a sample is lane ^ 1.
-__device__ __forceinline__ void p8_output(const alac_decode_params& p, const Meta& m, int mine, int ih, int n_out, int j,
-                                          int chan, int32_t* pcm_slot) {
-    const int cnt = min(8, n_out - ih);
-    const bool live = j < cnt;
-    const int i = m.esc ? ih + j : ih + cnt - 1 - j;
-    if (live && m.esc && (chan == 0 || m.stereo)) {
-        const uint32_t bp = m.rawbit + (uint32_t)((i * (m.stereo ? 2 : 1) + chan) * m.ss);
-        mine = __builtin_amdgcn_sbfe((int)peek_bits(m.base, m.limit, bp, m.ss), 0, m.ss);
-    }
-    const int partner = __builtin_amdgcn_update_dpp(0, mine, DPP_QUAD_1032, 0xF, 0xF, false);
-    if (live) {
-        const int a = chan == 0 ? mine : partner, b = chan == 0 ? partner : mine;
-        int val;
-        if (m.stereo) {
-            int left, right;
-            if (m.mixweight != 0) {
-                right = wsub(a, wmul(b, m.mixweight) >> (m.mixshift & 31));
-                left = wadd(right, b);
-            } else {
-                left = a;
-                right = b;
-            }
-            val = chan == 0 ? left : right;
-        } else {
-            val = chan == 0 ? a : 0;
-        }
-        if (m.ss == 24) {
-            if (m.ub != 0 && !m.esc && (chan == 0 || m.stereo)) {
-                const uint32_t bp = m.ubit + (uint32_t)((i * (m.stereo ? 2 : 1) + chan) * 8 * m.ub);
-                const uint32_t sb = peek_bits(m.base, m.limit, bp, 8 * m.ub);
-                val = (int)(((uint32_t)val << (8 * m.ub)) | sb);
-            }
-            val = __builtin_amdgcn_sbfe(val, 0, 24);
-        }
-        if (chan < m.nc) store_sample(p, m, pcm_slot, (int64_t)i * m.nc + chan, val);
-    }
-}
-
-// Reconstruction in the P8 layout (see alac_device.h): 8 streams = 4 packets per wave.  Two waves share the job:
-// the COMPUTE wave runs the FIR and drops each batch of 8 outputs per stream into an LDS queue; the OUTPUT wave (one
-// of the reconstruction waves the P8 layout leaves idle) picks them up one chunk later and does the un-mixing, shift
-// bytes and stores -- about a tenth of the instructions, taken off the longest chain of the main pass.
-template <int F, bool MONO, bool OUTPUT_ROLE>
-__device__ void recon8_wave(const alac_decode_params& p, uint32_t pkt0, int w8, int lane, SplitShared<F>& sh, int nchunks) {
-    constexpr int S = 4 * F;
-    const int row = lane >> 4, l = lane & 15, par = l & 1, j = l >> 1;
-    const int g = 8 * w8 + 2 * row + par;                  // stream index inside the workgroup
-    const int chan = stream_chan<MONO>(g);
-    const uint32_t pkt = pkt0 + (uint32_t)stream_packet<MONO>(g);
-    const bool valid = pkt < p.n_packets;
-    alacgpu_cfg_dev cfg;
-    const Meta m = parse_meta(p, pkt, chan, valid, cfg);
-    const bool compressed = valid && m.status == 0 && !m.esc;
-    const bool stream_on = compressed && (chan == 0 || m.stereo);
-    const int n_row = stream_on ? m.n : 0;
-    const int n_out = (valid && m.status == 0) ? m.n : 0;
-    int32_t* pcm_slot = p.pcm_out + (int64_t)pkt * p.slot_ints;
-
-    if (OUTPUT_ROLE) {
-        for (int c = 0; c <= nchunks; c++) {
-            wg_sync();  // barrier c (c == nchunks: the final one); chunk c-1's outputs are in the queue now
-            if (c == 0) continue;
-#pragma unroll
-            for (int half = 0; half < 2; half++)
-                p8_output(p, m, sh.outq[(c - 1) & 1][half][w8][lane], (c - 1) * CHUNK + 8 * half, n_out, j, chan, pcm_slot);
-        }
-        return;
-    }
-
-    Fir8Lane f;
-    f.hist = 0;
-    f.coef = (stream_on && j < m.N) ? (int)(int16_t)peek_bits(m.base, m.limit, m.coefbit + 16u * j, 16) : 0;
-    f.base = 0;
-    f.prev = 0;
-    f.q = stream_on ? m.q : 1;
-    f.rnd = stream_on ? m.rnd : 0;
-    f.rss = stream_on ? m.rss : 16;
-    f.qmask = (1 << f.q) - 1;
-    f.N = stream_on ? m.N : 0;
-    const bool tap = stream_on && j < m.N;
-    f.tlo = tap ? -1 : 0;
-    f.thi = tap ? 1 : 0;
-    f.w = tap ? (uint32_t)(m.N - j) : 0u;
-    f.bpaddr = ((lane & 48) + 2 * (stream_on ? (m.N - 1) & 7 : 0) + par) * 4;
-
-    const int nmax = __builtin_amdgcn_readfirstlane(wave_max(n_row));
-    const int nmin = __builtin_amdgcn_readfirstlane(-wave_max(stream_on ? -m.n : -0x7FFFFFFF));
-    const int* qzero = &sh.zeros[0][g];
-
-    for (int c = 0; c < nchunks; c++) {
-        const int i0 = c * CHUNK;
-        wg_sync();  // wait for chunk c
-        const int* q = stream_on ? &sh.resq[c & 1][0][g] : qzero;
-#pragma unroll
-        for (int half = 0; half < 2; half++) {             // 8 lanes of history per stream: hand over every 8 steps
-            const int ih = i0 + 8 * half;
-            if (ih < nmax) {
-                if (ih > 8 && ih + 8 <= nmin) {   // every switched-on stream is past its warm-up and has 8 samples left
-                    int err = q[(8 * half) * S];
-#pragma unroll
-                    for (int ii = 0; ii < 8; ii++) {
-                        const int en = q[(8 * half + (ii < 7 ? ii + 1 : ii)) * S];
-                        fir8_step<false>(f, err, ih + ii, true);
-                        err = en;
-                    }
-                } else {
-                    for (int ii = 0; ii < 8; ii++) {
-                        const int i = ih + ii;
-                        const int err = q[(8 * half + ii) * S];
-                        fir8_step<true>(f, err, i, i < n_row);
-                    }
-                }
-            }
-            sh.outq[c & 1][half][w8][lane] = f.hist;   // lane (2t + par) holds out[last - t] of its stream
-        }
-    }
-    wg_sync();  // final barrier: the last chunk's outputs are in the queue
-}
-
-template <int F, bool MONO>
-__device__ void recon_wave(const alac_decode_params& p, uint32_t pkt0, int w, int lane, SplitShared<F>& sh, int nchunks) {
-    // ---- can the whole workgroup use the P8 layout?  Every wave evaluates all 4F streams the same way. ----
-    bool p8 = true;
-    {
-        constexpr int S = 4 * F;
-#pragma unroll
-        for (int base = 0; base < S; base += 64) {
-            const int gg = base + (lane % S);
-            const uint32_t pk = pkt0 + (uint32_t)stream_packet<MONO>(gg);
-            const bool v = pk < p.n_packets;
-            const int gc = stream_chan<MONO>(gg);
-            alacgpu_cfg_dev c;
-            const Meta mm = parse_meta(p, pk, gc, v, c);
-            const bool on = v && mm.status == 0 && !mm.esc && (gc == 0 || mm.stereo);
-            const bool bad = on && (mm.N < 1 || mm.N > 8);
-            if (__builtin_amdgcn_ballot_w64(bad)) p8 = false;
-        }
-    }
-    if (p8 && F >= 2) {
-        if (w < F / 2) recon8_wave<F, MONO, false>(p, pkt0, w, lane, sh, nchunks);          // FIR
-        else recon8_wave<F, MONO, true>(p, pkt0, w - F / 2, lane, sh, nchunks);            // un-mix + store
-        return;
-    }
-    const int row = lane >> 4;
-    const int g = 4 * w + row;
-    const int chan = stream_chan<MONO>(g);
-    const uint32_t pkt = pkt0 + (uint32_t)stream_packet<MONO>(g);
-    const bool valid = pkt < p.n_packets;
-    alacgpu_cfg_dev cfg;
-    const Meta m = parse_meta(p, pkt, chan, valid, cfg);
-    const bool wide = valid && m.status == 0 && !m.esc && m.N > 16 && (chan == 0 || m.stereo);   // incl. N == 31 (delta mode)
-    if (__builtin_amdgcn_ballot_w64(wide))
-        recon_wave_impl<F, 2>(p, m, valid, g, chan, lane, sh, nchunks, pkt);
-    else
-        recon_wave_impl<F, 1>(p, m, valid, g, chan, lane, sh, nchunks, pkt);
-}
-
-template <int F, bool MONO>
-__device__ __forceinline__ void split_kernel_body(const alac_decode_params& p) {
-    __shared__ __attribute__((aligned(1024))) SplitShared<F> sh;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    constexpr int PPW = MONO ? 4 * F : 2 * F;              // packets per workgroup
-    const uint32_t pkt0 = blockIdx.x * (uint32_t)PPW;
-    if (p.ab_flags && p.ab_flags[pkt0 >> 3] != 1u) return;   // a two-pass kernel decoded this group of 8 already
-    // chunk count must be uniform over the workgroup: every wave derives it from all 2F headers
-    int n_any = 0;
-    {
-        const uint32_t pk = pkt0 + (uint32_t)(lane % PPW);
-        const bool v = pk < p.n_packets;
-        alacgpu_cfg_dev c;
-        const Meta mm = parse_meta(p, pk, 0, v, c);
-        n_any = (v && mm.status == 0) ? mm.n : 0;
-    }
-    const int nall = __builtin_amdgcn_readfirstlane(wave_max(n_any));
-    const int nchunks = (nall + CHUNK - 1) / CHUNK;
-    for (int t = threadIdx.x; t < CHUNK * 4 * F; t += blockDim.x) (&sh.zeros[0][0])[t] = 0;
-    wg_sync();
-    if (wave == 0) {
-        // the entropy wave is the longest dependent chain of the workgroup: let it win issue arbitration
-        __builtin_amdgcn_s_setprio(ALAC_ENTROPY_PRIO);
-        entropy_wave<F, MONO>(p, pkt0, lane, sh, nchunks);
-    }
-    else {
-        recon_wave<F, MONO>(p, pkt0, wave - 1, lane, sh, nchunks);
-    }
-}
-
 
 // ===================================================================================================================
 // v3 "two-pass" kernels: 8 packets per workgroup, three working waves (entropy, output, FIR; which wave takes which role
@@ -1422,11 +631,11 @@ struct AbRefill {
         const uint32_t pk = pkt0 + (uint32_t)r;
         base = p.blob;
         limit = 0;
-        if (pk < p.n_packets) {                // as parse_meta: 16-byte aligned-down packet start, readable bytes from it
+        if (pk < p.n_packets) {                // as parse_meta: 16-byte aligned-down packet start, bytes up to the packet's end
             const uint64_t off = p.offsets[pk];
             const uint64_t al = off - (off & 15u);
             base = p.blob + al;
-            limit = (int64_t)p.blob_limit - (int64_t)al;
+            limit = min((int64_t)p.blob_limit - (int64_t)al, (int64_t)(off & 15u) + (int64_t)p.sizes[pk]);
         }
     }
     // after a barrier: look at how far the stream has read and load what fits (first: a pass starts, take over `filled`)
@@ -1439,8 +648,7 @@ struct AbRefill {
         for (int k = 0; k < ROUNDS; k++) {
             v[k] = make_uint4(0, 0, 0, 0);
             if (on && filled + (uint32_t)(k + 1) * 128u <= (next - 12u) + RING_BYTES) {
-                const int64_t off = (int64_t)filled + (int64_t)k * 128 + sub * 16;
-                if (off + 16 <= limit) v[k] = *reinterpret_cast<const uint4*>(base + off);
+                v[k] = load16_clamped(base, (int64_t)filled + (int64_t)k * 128 + sub * 16, limit);
                 cnt = (uint32_t)(k + 1);
             }
         }
@@ -1669,9 +877,3 @@ __device__ __forceinline__ void ab_kernel_body(const alac_decode_params& p) {
 extern "C" __global__ __launch_bounds__(256, 5) void alac_decode_ab_kernel(alac_decode_params p) { ab_kernel_body<8>(p); }
 // LPC orders up to 31 (and the delta mode): two FIR waves in the 16-lane layout with two tap registers, four packets each
 extern "C" __global__ __launch_bounds__(256) void alac_decode_ab32_kernel(alac_decode_params p) { ab_kernel_body<16>(p); }
-extern "C" __global__ __launch_bounds__(128) void alac_decode_split1_kernel(alac_decode_params p) { split_kernel_body<1, false>(p); }
-extern "C" __global__ __launch_bounds__(192) void alac_decode_split2_kernel(alac_decode_params p) { split_kernel_body<2, false>(p); }
-extern "C" __global__ __launch_bounds__(320, 6) void alac_decode_split4_kernel(alac_decode_params p) { split_kernel_body<4, false>(p); }
-// one-channel streams: 8 / 16 packets per workgroup, no pre-scan
-extern "C" __global__ __launch_bounds__(192) void alac_decode_split2_mono_kernel(alac_decode_params p) { split_kernel_body<2, true>(p); }
-extern "C" __global__ __launch_bounds__(320, 6) void alac_decode_split4_mono_kernel(alac_decode_params p) { split_kernel_body<4, true>(p); }

@@ -1,5 +1,5 @@
 // alacgpu_api.hip -- C ABI of include/alacgpu.h on top of the gfx950 kernels.
-// No CPU fallback anywhere in this file: every decode goes through alac_decode_packets_kernel.
+// No CPU fallback anywhere in this file: every decode goes through alac_decode_ab_kernel / alac_decode_ab32_kernel.
 #include <hip/hip_runtime.h>
 #include <algorithm>
 
@@ -14,25 +14,40 @@
 
 static_assert(sizeof(alacgpu_cfg) == sizeof(alacgpu_cfg_dev), "cfg layouts must match");
 
+namespace {
+
+constexpr int N_SLOTS = 8;          // launch pairs that may be in flight at once on one ctx (any streams)
+constexpr int N_HOST_STREAMS = 4;   // chunks of the host-buffer pipeline (H2D k+1 || decode k || D2H k-1)
+
+// What one launch pair (alac_decode_ab_kernel + alac_decode_ab32_kernel) owns while it is in flight: the group flags the
+// first kernel hands to the second, and the events that bracket the pair.  A slot is reused only after its last launch
+// has finished (hipEventSynchronize), so calls on different streams never share flags.
+struct launch_slot {
+    uint32_t* d_flags = nullptr;
+    size_t flags_n = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool used = false;
+};
+
+}  // namespace
+
 struct alacgpu_ctx {
     int device = 0;
     uint32_t n_cfgs = 0;
     alacgpu_cfg* h_cfgs = nullptr;
     alacgpu_cfg_dev* d_cfgs = nullptr;
-    hipStream_t stream = nullptr;      // used by the host-buffer entry points
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool timed = false;
+    hipStream_t streams[N_HOST_STREAMS] = {};   // used by the host-buffer entry points
+    hipEvent_t ev_meta = nullptr;
+    launch_slot slots[N_SLOTS];
+    unsigned next_slot = 0;
+    int last_slot = -1;
     uint32_t out_format = 0;           // 0 int32 per sample, 1 packed little-endian PCM
-    bool all_mono = false;             // every stream cfg has one channel -> the *_mono kernels
-    int variant = 0;                   // 0 auto, 1 fused (v1), 2/3/4 split with 1/2/4 reconstruction waves, 5 two-pass
-    uint32_t* d_cu_arrivals = nullptr; // two-pass kernels: per-CU workgroup counters (alac_decode_params::cu_arrivals)
-    uint32_t* d_ab_flags = nullptr;    // two-pass kernel -> fallback launch protocol (one flag per 8 packets), grow-only
-    size_t ab_flags_n = 0;
+    int host_chunks = 0;               // 0 auto; 1..N_HOST_STREAMS forced (ALACGPU_HOST_CHUNKS, A/B only)
+    uint32_t* d_cu_arrivals = nullptr; // per-CU workgroup counters (alac_decode_params::cu_arrivals)
     // grow-only device workspace for the host-buffer entry points
     void* d_ws = nullptr;
     size_t ws_bytes = 0;
-    void* h_pin = nullptr;             // pinned staging for small single-frame calls
-    size_t pin_bytes = 0;
+    int32_t* h_frame = nullptr;        // pinned staging of alacgpu_decode_frame (one slot of the widest kind)
     std::string last_error;
 };
 
@@ -51,6 +66,8 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 int ensure_ws(alacgpu_ctx* ctx, size_t bytes) {
     if (bytes <= ctx->ws_bytes) return ALACGPU_OK;
+    for (int i = 0; i < N_HOST_STREAMS; i++)
+        if (ctx->streams[i]) HIP_TRY(ctx, hipStreamSynchronize(ctx->streams[i]));
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
     ctx->d_ws = nullptr;
     ctx->ws_bytes = 0;
@@ -60,76 +77,74 @@ int ensure_ws(alacgpu_ctx* ctx, size_t bytes) {
     return ALACGPU_OK;
 }
 
+// The two-pass kernels: the main one decodes the groups of 8 packets whose streams have LPC order 1..16 and flags the
+// others for the 32-tap arrangement launched right behind it on the same stream (a two-channel packet passes the header
+// check only in a two-channel stream cfg, where its slot has room for parking; the kernel reports a status otherwise).
 int launch(alacgpu_ctx* ctx, const alac_decode_params& p_in, hipStream_t stream) {
     if (p_in.n_packets == 0) return ALACGPU_OK;
     alac_decode_params p = p_in;
-    p.ab_flags = nullptr;
     p.cu_arrivals = ctx->d_cu_arrivals;
-    int variant = ctx->variant;
-    // auto: the two-pass kernels (no Rice pre-scan; cfg2 0.99 -> 0.81 ms).  The main one decodes the groups of 8 packets
-    // whose streams have LPC order 1..16 and flags the others for the 32-tap arrangement launched right behind it on the
-    // same stream.  The split kernels (variants 2..4: 2 / 4 / 8 packets per workgroup, twice that for one-channel cfgs)
-    // remain as A/B references, and variant 4 as the choice for one-channel cfgs in very big batches.
-    // One-channel cfgs finish in the two-pass kernel's first pass (8 packets per workgroup, no parking); measured on cfg4,
-    // two-pass / 16-packet split workgroups: 4096 packets 0.44 / 0.78 ms, 8192 0.57 / 0.81, 12288 0.98 / 0.87,
-    // 16384 1.20 / 0.93, 24576 1.60 / 1.91, 32768 2.07 / 2.65: the split kernel wins only where its 1024 workgroups
-    // all fit at once and the two-pass kernel's do not.
-    if (variant == 0) variant = (ctx->all_mono && p.n_packets > 10240u && p.n_packets <= 20480u) ? 4 : 5;
-    HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
-    if (variant == 5) {
-        const size_t groups = ((size_t)p.n_packets + 7) / 8;
-        if (groups > ctx->ab_flags_n) {
-            if (ctx->d_ab_flags) (void)hipFree(ctx->d_ab_flags);
-            ctx->d_ab_flags = nullptr;
-            ctx->ab_flags_n = 0;
-            const size_t want = groups + groups / 4 + 64;
-            HIP_TRY(ctx, hipMalloc((void**)&ctx->d_ab_flags, want * sizeof(uint32_t)));
-            ctx->ab_flags_n = want;
-        }
-        p.ab_flags = ctx->d_ab_flags;
-        alac_decode_params args = p;
-        void* kargs[] = {&args};
-        HIP_TRY(ctx, hipLaunchKernel((const void*)alac_decode_ab_kernel, dim3((uint32_t)groups), dim3(256), kargs, 0, stream));
-        // what it flagged -> the 32-tap arrangement of the same kernel, which takes every LPC order and so everything that
-        // is left (a two-channel packet passes the header check only in a two-channel stream cfg, where its slot has room
-        // for parking; the kernel reports a status if that ever fails).  Variants 2..4 remain as A/B references and for
-        // one-channel cfgs in very big batches.
-        HIP_TRY(ctx, hipLaunchKernel((const void*)alac_decode_ab32_kernel, dim3((uint32_t)groups), dim3(256), kargs, 0, stream));
-        HIP_TRY(ctx, hipGetLastError());
-        HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
-        ctx->timed = true;
-        return ALACGPU_OK;
+    const int si = (int)(ctx->next_slot++ % N_SLOTS);
+    launch_slot& sl = ctx->slots[si];
+    if (sl.used) HIP_TRY(ctx, hipEventSynchronize(sl.ev1));   // the pair that last used these flags has finished
+    const size_t groups = ((size_t)p.n_packets + 7) / 8;
+    if (groups > sl.flags_n) {
+        if (sl.d_flags) (void)hipFree(sl.d_flags);
+        sl.d_flags = nullptr;
+        sl.flags_n = 0;
+        const size_t want = groups + groups / 4 + 64;
+        HIP_TRY(ctx, hipMalloc((void**)&sl.d_flags, want * sizeof(uint32_t)));
+        sl.flags_n = want;
     }
-    // Pick the kernel and its geometry.
-    const void* fn = nullptr;
-    uint32_t ppw = 2, threads = 64;    // packets per workgroup, workgroup size
-    switch (variant) {
-    case 1: fn = (const void*)alac_decode_packets_kernel; ppw = 2; threads = 64; break;
-    case 2: fn = (const void*)alac_decode_split1_kernel; ppw = 2; threads = 128; break;
-    case 4:
-        if (ctx->all_mono) { fn = (const void*)alac_decode_split4_mono_kernel; ppw = 16; }
-        else { fn = (const void*)alac_decode_split4_kernel; ppw = 8; }
-        threads = 320;
-        break;
-    default:
-        if (ctx->all_mono) { fn = (const void*)alac_decode_split2_mono_kernel; ppw = 8; }
-        else { fn = (const void*)alac_decode_split2_kernel; ppw = 4; }
-        threads = 192;
-        break;
-    }
-    const uint32_t grid = (p.n_packets + ppw - 1) / ppw;
-    // (Workgroup placement was checked with HW_ID stamps: a 1024-workgroup grid lands as exactly 4 per CU on all
-    // 256 CUs, so no occupancy padding is needed to balance it.)
-    const uint32_t dyn_lds = 0;
-    {
-        alac_decode_params args = p;
-        void* kargs[] = {&args};
-        HIP_TRY(ctx, hipLaunchKernel(fn, dim3(grid), dim3(threads), kargs, dyn_lds, stream));
-    }
+    p.ab_flags = sl.d_flags;
+    HIP_TRY(ctx, hipEventRecord(sl.ev0, stream));
+    alac_decode_params args = p;
+    void* kargs[] = {&args};
+    HIP_TRY(ctx, hipLaunchKernel((const void*)alac_decode_ab_kernel, dim3((uint32_t)groups), dim3(256), kargs, 0, stream));
+    HIP_TRY(ctx, hipLaunchKernel((const void*)alac_decode_ab32_kernel, dim3((uint32_t)groups), dim3(256), kargs, 0, stream));
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
-    ctx->timed = true;
+    HIP_TRY(ctx, hipEventRecord(sl.ev1, stream));
+    sl.used = true;
+    ctx->last_slot = si;
     return ALACGPU_OK;
+}
+
+int fill_params(alacgpu_ctx* ctx, alac_decode_params& p, const void* d_blob, uint64_t blob_bytes, const void* d_offsets,
+                const void* d_sizes, const void* d_cfg_idx, uint32_t n_packets, void* d_pcm_out, uint32_t slot_ints,
+                void* d_out_bytes, void* d_out_samples, void* d_status) {
+    if (!d_blob || !d_offsets || !d_sizes || !d_pcm_out || !d_status || slot_ints == 0) return ALACGPU_ERR_BAD_ARG;
+    if (((uintptr_t)d_blob & 15u) != 0 || ((uintptr_t)d_offsets & 7u) != 0 || ((uintptr_t)d_sizes & 3u) != 0 ||
+        ((uintptr_t)d_pcm_out & 3u) != 0 || ((uintptr_t)d_status & 3u) != 0 || ((uintptr_t)d_cfg_idx & 1u) != 0 ||
+        ((uintptr_t)d_out_bytes & 3u) != 0 || ((uintptr_t)d_out_samples & 3u) != 0)
+        return ALACGPU_ERR_BAD_ARG;
+    p.blob = (const uint8_t*)d_blob;
+    p.blob_limit = align_up(blob_bytes, 16);
+    p.offsets = (const uint64_t*)d_offsets;
+    p.sizes = (const uint32_t*)d_sizes;
+    p.cfg_idx = (const uint16_t*)d_cfg_idx;
+    p.cfgs = ctx->d_cfgs;
+    p.n_cfgs = ctx->n_cfgs;
+    p.n_packets = n_packets;
+    p.pcm_out = (int32_t*)d_pcm_out;
+    p.slot_ints = slot_ints;
+    p.out_bytes = (int32_t*)d_out_bytes;
+    p.out_samples = (int32_t*)d_out_samples;
+    p.status = (int32_t*)d_status;
+    p.out_format = ctx->out_format;
+    p.dbg = nullptr;
+    p.ab_flags = nullptr;
+    p.cu_arrivals = nullptr;
+    return ALACGPU_OK;
+}
+
+// bytes per sample the packed format can put into a slot (2 or 3; the widest stream cfg decides)
+size_t packed_bytes_per_slot_int(const alacgpu_ctx* ctx) {
+    size_t bps = 2;
+    for (uint32_t i = 0; i < ctx->n_cfgs; i++) {
+        const int ss = ctx->h_cfgs[i].ctor_sample_size ? ctx->h_cfgs[i].ctor_sample_size : ctx->h_cfgs[i].sample_size;
+        bps = std::max(bps, (size_t)std::min(std::max(ss / 8, 2), 4));
+    }
+    return bps;
 }
 
 }  // namespace
@@ -166,6 +181,17 @@ const char* alacgpu_status_string(int st) {
 
 const char* alacgpu_last_error(alacgpu_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null ctx"; }
 
+int alacgpu_device_count(void) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return 0;
+    int usable = 0;
+    for (int d = 0; d < ndev; d++) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d) == hipSuccess && std::strncmp(prop.gcnArchName, "gfx950", 6) == 0) usable++;
+    }
+    return usable;
+}
+
 int alacgpu_cfg_from_codec_data(const int32_t* in, uint32_t n_ints, int samplesize, int numchannels, alacgpu_cfg* c) {
     if (!in || !c || n_ints < 48) return ALACGPU_ERR_BAD_ARG;
     std::memset(c, 0, sizeof(*c));
@@ -197,9 +223,7 @@ int alacgpu_create(const alacgpu_cfg* cfgs, uint32_t n_cfgs, int device, alacgpu
     if (!ctx) return ALACGPU_ERR_NO_MEMORY;
     ctx->device = device;
     ctx->n_cfgs = n_cfgs;
-    ctx->all_mono = true;
-    for (uint32_t i = 0; i < n_cfgs; i++) ctx->all_mono = ctx->all_mono && cfgs[i].num_channels == 1;
-    if (const char* v = std::getenv("ALACGPU_KERNEL_VARIANT")) ctx->variant = std::atoi(v) >= 0 && std::atoi(v) <= 5 ? std::atoi(v) : 0;
+    if (const char* v = std::getenv("ALACGPU_HOST_CHUNKS")) ctx->host_chunks = std::max(0, std::min(std::atoi(v), N_HOST_STREAMS));
     int rc = ALACGPU_OK;
     do {
         if (hipSetDevice(device) != hipSuccess) { rc = ALACGPU_ERR_NO_DEVICE; break; }
@@ -208,8 +232,13 @@ int alacgpu_create(const alacgpu_cfg* cfgs, uint32_t n_cfgs, int device, alacgpu
         std::memcpy(ctx->h_cfgs, cfgs, sizeof(alacgpu_cfg) * n_cfgs);
         if (hipMalloc((void**)&ctx->d_cfgs, sizeof(alacgpu_cfg_dev) * n_cfgs) != hipSuccess) { rc = ALACGPU_ERR_HIP; break; }
         if (hipMemcpy(ctx->d_cfgs, cfgs, sizeof(alacgpu_cfg) * n_cfgs, hipMemcpyHostToDevice) != hipSuccess) { rc = ALACGPU_ERR_HIP; break; }
-        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { rc = ALACGPU_ERR_HIP; break; }
-        if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) { rc = ALACGPU_ERR_HIP; break; }
+        bool ok = true;
+        for (int i = 0; i < N_HOST_STREAMS && ok; i++)
+            ok = hipStreamCreateWithFlags(&ctx->streams[i], hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&ctx->ev_meta, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; i < N_SLOTS && ok; i++)
+            ok = hipEventCreate(&ctx->slots[i].ev0) == hipSuccess && hipEventCreate(&ctx->slots[i].ev1) == hipSuccess;
+        if (!ok) { rc = ALACGPU_ERR_HIP; break; }
         if (hipMalloc((void**)&ctx->d_cu_arrivals, 2048 * sizeof(uint32_t)) != hipSuccess ||
             hipMemset(ctx->d_cu_arrivals, 0, 2048 * sizeof(uint32_t)) != hipSuccess) { rc = ALACGPU_ERR_HIP; break; }
     } while (0);
@@ -224,17 +253,34 @@ int alacgpu_create(const alacgpu_cfg* cfgs, uint32_t n_cfgs, int device, alacgpu
 void alacgpu_destroy(alacgpu_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < N_HOST_STREAMS; i++)
+        if (ctx->streams[i]) (void)hipStreamSynchronize(ctx->streams[i]);
+    for (int i = 0; i < N_SLOTS; i++) {
+        launch_slot& sl = ctx->slots[i];
+        if (sl.used) (void)hipEventSynchronize(sl.ev1);   // device-pointer calls on the caller's streams
+        if (sl.d_flags) (void)hipFree(sl.d_flags);
+        if (sl.ev0) (void)hipEventDestroy(sl.ev0);
+        if (sl.ev1) (void)hipEventDestroy(sl.ev1);
+    }
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
     if (ctx->d_cu_arrivals) (void)hipFree(ctx->d_cu_arrivals);
-    if (ctx->d_ab_flags) (void)hipFree(ctx->d_ab_flags);
-    if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+    if (ctx->h_frame) (void)hipHostFree(ctx->h_frame);
     if (ctx->d_cfgs) (void)hipFree(ctx->d_cfgs);
-    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
-    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->ev_meta) (void)hipEventDestroy(ctx->ev_meta);
+    for (int i = 0; i < N_HOST_STREAMS; i++)
+        if (ctx->streams[i]) (void)hipStreamDestroy(ctx->streams[i]);
     std::free(ctx->h_cfgs);
     delete ctx;
+}
+
+void* alacgpu_alloc_pinned(size_t bytes) {
+    void* p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+void alacgpu_free_pinned(void* p) {
+    if (p) (void)hipHostFree(p);
 }
 
 int alacgpu_decode_batch_device(alacgpu_ctx* ctx, const void* d_blob, uint64_t blob_bytes, const void* d_offsets,
@@ -243,69 +289,68 @@ int alacgpu_decode_batch_device(alacgpu_ctx* ctx, const void* d_blob, uint64_t b
                                 void* hip_stream) {
     if (!ctx) return ALACGPU_ERR_BAD_ARG;
     if (n_packets == 0) return ALACGPU_OK;
-    if (!d_blob || !d_offsets || !d_sizes || !d_pcm_out || !d_status || slot_ints == 0) return ALACGPU_ERR_BAD_ARG;
-    if (((uintptr_t)d_blob & 15u) != 0) return ALACGPU_ERR_BAD_ARG;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
     alac_decode_params p;
-    p.blob = (const uint8_t*)d_blob;
-    p.blob_limit = align_up(blob_bytes, 16);
-    p.offsets = (const uint64_t*)d_offsets;
-    p.sizes = (const uint32_t*)d_sizes;
-    p.cfg_idx = (const uint16_t*)d_cfg_idx;
-    p.cfgs = ctx->d_cfgs;
-    p.n_cfgs = ctx->n_cfgs;
-    p.n_packets = n_packets;
-    p.pcm_out = (int32_t*)d_pcm_out;
-    p.slot_ints = slot_ints;
-    p.out_bytes = (int32_t*)d_out_bytes;
-    p.out_samples = (int32_t*)d_out_samples;
-    p.status = (int32_t*)d_status;
-    p.out_format = ctx->out_format;
-    p.dbg = nullptr;
-    if (std::getenv("ALACGPU_DEBUG_STAMPS")) {  // diagnostic: per-WG phase stamps, printed to stderr (blocks)
-        const uint32_t nwg = (n_packets + 1) / 2;
-        unsigned long long* d = nullptr;
-        HIP_TRY(ctx, hipMalloc((void**)&d, sizeof(unsigned long long) * 8 * nwg));
-        HIP_TRY(ctx, hipMemset(d, 0, sizeof(unsigned long long) * 8 * nwg));
-        p.dbg = d;
-        int rc = launch(ctx, p, (hipStream_t)hip_stream);
-        HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)hip_stream));
-        unsigned long long* h = (unsigned long long*)std::malloc(sizeof(unsigned long long) * 8 * nwg);
-        HIP_TRY(ctx, hipMemcpy(h, d, sizeof(unsigned long long) * 8 * nwg, hipMemcpyDeviceToHost));
-        double acc[8] = {0}; uint32_t cnt = 0;
-        double mx_end = 0, mn_end = 1e30, mx_pre = 0; unsigned long long t_first = ~0ull, t_last = 0;
-        for (uint32_t w = 0; w < nwg; w++) {
-            if (!h[8 * w]) continue;
-            cnt++;
-            for (int j = 1; j < 8; j++) acc[j] += (double)(h[8 * w + j] - h[8 * w]);
-            const double e = (double)(h[8 * w + 2] - h[8 * w]);
-            mx_end = e > mx_end ? e : mx_end; mn_end = e < mn_end ? e : mn_end;
-            const double pe = (double)(h[8 * w + 1] - h[8 * w]);
-            mx_pre = pe > mx_pre ? pe : mx_pre;
-            if (h[8 * w] < t_first) t_first = h[8 * w];
-            if (h[8 * w + 2] > t_last) t_last = h[8 * w + 2];
-        }
-        if (cnt) std::fprintf(stderr, "[alacgpu stamps] per-WG entropy_end min=%.0f max=%.0f  prescan_end max=%.0f  first WG start -> last WG end = %.0f\n",
-                              mn_end, mx_end, mx_pre, (double)(t_last - t_first));
-        if (cnt) std::fprintf(stderr, "[alacgpu stamps] wgs=%u  prescan_end=%.0f  entropy_end=%.0f  recon_first_chunk=%.0f  recon_end=%.0f  entropy_barrier_wait=%.0f  recon_barrier_wait=%.0f (cycles from WG start)  main_units_redone=%.1f per WG\n",
-                              cnt, acc[1] / cnt, acc[2] / cnt, acc[3] / cnt, acc[4] / cnt, acc[5] / cnt, acc[6] / cnt, acc[7] / cnt);
-        if (const char* dump = std::getenv("ALACGPU_DEBUG_STAMPS_FILE")) {   // raw per-WG stamps for offline analysis
-            if (FILE* f = std::fopen(dump, "wb")) { std::fwrite(h, sizeof(unsigned long long), (size_t)8 * nwg, f); std::fclose(f); }
-        }
-        std::free(h); (void)hipFree(d);
-        return rc;
-    }
+    int rc = fill_params(ctx, p, d_blob, blob_bytes, d_offsets, d_sizes, d_cfg_idx, n_packets, d_pcm_out, slot_ints,
+                         d_out_bytes, d_out_samples, d_status);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
     return launch(ctx, p, (hipStream_t)hip_stream);
 }
 
+// Diagnostic twin of alacgpu_decode_batch_device (not part of include/alacgpu.h; tools/ only): the kernels additionally
+// write 8 clock / placement stamps per workgroup into d_stamps (8 * ceil(n_packets / 8) uint64, zeroed by the caller).
+int alacgpu_dbg_decode_batch_device_stamps(alacgpu_ctx* ctx, const void* d_blob, uint64_t blob_bytes, const void* d_offsets,
+                                           const void* d_sizes, const void* d_cfg_idx, uint32_t n_packets, void* d_pcm_out,
+                                           uint32_t slot_ints, void* d_out_bytes, void* d_out_samples, void* d_status,
+                                           void* hip_stream, void* d_stamps) {
+    if (!ctx || !d_stamps) return ALACGPU_ERR_BAD_ARG;
+    if (n_packets == 0) return ALACGPU_OK;
+    alac_decode_params p;
+    int rc = fill_params(ctx, p, d_blob, blob_bytes, d_offsets, d_sizes, d_cfg_idx, n_packets, d_pcm_out, slot_ints,
+                         d_out_bytes, d_out_samples, d_status);
+    if (rc) return rc;
+    p.dbg = (unsigned long long*)d_stamps;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return launch(ctx, p, (hipStream_t)hip_stream);
+}
+
+// Host buffers: the batch is cut into up to four contiguous packet ranges, each on its own stream, so that the H2D copy of
+// range k+1, the decode of range k and the D2H copy of range k-1 overlap (the two copy directions use different DMA
+// engines).  Issue order: all uploads and launches first, then the downloads in range order.
 int alacgpu_decode_batch(alacgpu_ctx* ctx, const uint8_t* blob, uint64_t blob_bytes, const uint64_t* offsets,
                          const uint32_t* sizes, const uint16_t* cfg_idx, uint32_t n_packets, int32_t* pcm_out,
                          uint32_t slot_ints, int32_t* out_bytes, int32_t* out_samples, int32_t* status) {
     if (!ctx) return ALACGPU_ERR_BAD_ARG;
     if (n_packets == 0) return ALACGPU_OK;
     if (!blob || !offsets || !sizes || !pcm_out || !status || slot_ints == 0) return ALACGPU_ERR_BAD_ARG;
-    for (uint32_t i = 0; i < n_packets; i++)
-        if (offsets[i] > blob_bytes || (uint64_t)sizes[i] > blob_bytes - offsets[i]) return ALACGPU_ERR_BAD_ARG;
+    int nch = ctx->host_chunks ? ctx->host_chunks : (n_packets >= 2048u ? 4 : n_packets >= 512u ? 2 : 1);
+    nch = std::min<int>(nch, (int)n_packets);
+    // validate, and find the blob range every chunk needs
+    uint32_t lo[N_HOST_STREAMS + 1];
+    uint64_t b0[N_HOST_STREAMS], b1[N_HOST_STREAMS];
+    for (int k = 0; k <= nch; k++) lo[k] = (uint32_t)(((uint64_t)n_packets * (uint64_t)k / (uint64_t)nch + 7u) & ~7ull);
+    lo[0] = 0;
+    lo[nch] = n_packets;
+    for (int k = 1; k < nch; k++) lo[k] = std::min(lo[k], n_packets);   // (multiples of 8: whole groups of the kernel)
+    uint64_t range_sum = 0;
+    for (int k = 0; k < nch; k++) {
+        b0[k] = blob_bytes;
+        b1[k] = 0;
+        for (uint32_t i = lo[k]; i < lo[k + 1]; i++) {
+            if (offsets[i] > blob_bytes || (uint64_t)sizes[i] > blob_bytes - offsets[i]) return ALACGPU_ERR_BAD_ARG;
+            b0[k] = std::min(b0[k], offsets[i]);
+            b1[k] = std::max(b1[k], offsets[i] + sizes[i]);
+        }
+        if (b1[k] < b0[k]) b0[k] = b1[k] = 0;
+        b0[k] &= ~(uint64_t)15;
+        range_sum += b1[k] - b0[k];
+    }
+    if (nch > 1 && range_sum > blob_bytes + blob_bytes / 2) {   // packets not laid out in batch order: one upload
+        nch = 1;
+        lo[1] = n_packets;
+        b0[0] = 0;
+        b1[0] = blob_bytes;
+    }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     // workspace carve-up (all 256-byte aligned)
     const size_t blob_sz = align_up(blob_bytes + 64, 256);
@@ -318,39 +363,48 @@ int alacgpu_decode_batch(alacgpu_ctx* ctx, const uint8_t* blob, uint64_t blob_by
     if (rc) return rc;
     uint8_t* w = (uint8_t*)ctx->d_ws;
     uint8_t* d_blob = w; w += blob_sz;
-    uint8_t* d_off = w; w += off_sz;
-    uint8_t* d_sz = w; w += sz_sz;
-    uint8_t* d_ci = w; w += ci_sz;
-    uint8_t* d_ob = w; w += i32_sz;
-    uint8_t* d_os = w; w += i32_sz;
-    uint8_t* d_st = w; w += i32_sz;
-    uint8_t* d_pcm = w;
-    hipStream_t s = ctx->stream;
-    HIP_TRY(ctx, hipMemcpyAsync(d_blob, blob, blob_bytes, hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemsetAsync(d_blob + blob_bytes, 0, blob_sz - blob_bytes, s));
-    HIP_TRY(ctx, hipMemcpyAsync(d_off, offsets, sizeof(uint64_t) * n_packets, hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync(d_sz, sizes, sizeof(uint32_t) * n_packets, hipMemcpyHostToDevice, s));
-    if (cfg_idx) HIP_TRY(ctx, hipMemcpyAsync(d_ci, cfg_idx, sizeof(uint16_t) * n_packets, hipMemcpyHostToDevice, s));
-    rc = alacgpu_decode_batch_device(ctx, d_blob, blob_bytes, d_off, d_sz, cfg_idx ? d_ci : nullptr, n_packets, d_pcm,
-                                     slot_ints, d_ob, d_os, d_st, s);
-    if (rc) return rc;
-    if (ctx->out_format == ALACGPU_OUT_PACKED_LE) {
-        // a slot holds at most slot_ints samples of (ctor sample size / 8) bytes: copy that much of every slot
-        size_t bps = 2;
-        for (uint32_t i = 0; i < ctx->n_cfgs; i++) {
-            const int ss = ctx->h_cfgs[i].ctor_sample_size ? ctx->h_cfgs[i].ctor_sample_size : ctx->h_cfgs[i].sample_size;
-            bps = std::max(bps, (size_t)std::min(std::max(ss / 8, 2), 4));
-        }
-        const size_t pitch = sizeof(int32_t) * (size_t)slot_ints;
-        HIP_TRY(ctx, hipMemcpy2DAsync(pcm_out, pitch, d_pcm, pitch, std::min(pitch, bps * (size_t)slot_ints), n_packets,
-                                      hipMemcpyDeviceToHost, s));
-    } else {
-        HIP_TRY(ctx, hipMemcpyAsync(pcm_out, d_pcm, sizeof(int32_t) * (size_t)n_packets * slot_ints, hipMemcpyDeviceToHost, s));
+    uint64_t* d_off = (uint64_t*)w; w += off_sz;
+    uint32_t* d_sz = (uint32_t*)w; w += sz_sz;
+    uint16_t* d_ci = (uint16_t*)w; w += ci_sz;
+    int32_t* d_ob = (int32_t*)w; w += i32_sz;
+    int32_t* d_os = (int32_t*)w; w += i32_sz;
+    int32_t* d_st = (int32_t*)w; w += i32_sz;
+    int32_t* d_pcm = (int32_t*)w;
+    hipStream_t s0 = ctx->streams[0];
+    HIP_TRY(ctx, hipMemcpyAsync(d_off, offsets, sizeof(uint64_t) * n_packets, hipMemcpyHostToDevice, s0));
+    HIP_TRY(ctx, hipMemcpyAsync(d_sz, sizes, sizeof(uint32_t) * n_packets, hipMemcpyHostToDevice, s0));
+    if (cfg_idx) HIP_TRY(ctx, hipMemcpyAsync(d_ci, cfg_idx, sizeof(uint16_t) * n_packets, hipMemcpyHostToDevice, s0));
+    if (nch > 1) HIP_TRY(ctx, hipEventRecord(ctx->ev_meta, s0));
+    for (int k = 0; k < nch; k++) {
+        hipStream_t s = ctx->streams[k];
+        const uint32_t cnt = lo[k + 1] - lo[k];
+        if (cnt == 0) continue;
+        if (k > 0) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_meta, 0));
+        if (b1[k] > b0[k]) HIP_TRY(ctx, hipMemcpyAsync(d_blob + b0[k], blob + b0[k], b1[k] - b0[k], hipMemcpyHostToDevice, s));
+        rc = alacgpu_decode_batch_device(ctx, d_blob, blob_bytes, d_off + lo[k], d_sz + lo[k], cfg_idx ? d_ci + lo[k] : nullptr,
+                                         cnt, d_pcm + (size_t)lo[k] * slot_ints, slot_ints, d_ob + lo[k], d_os + lo[k],
+                                         d_st + lo[k], s);
+        if (rc) return rc;
     }
-    HIP_TRY(ctx, hipMemcpyAsync(status, d_st, sizeof(int32_t) * n_packets, hipMemcpyDeviceToHost, s));
-    if (out_bytes) HIP_TRY(ctx, hipMemcpyAsync(out_bytes, d_ob, sizeof(int32_t) * n_packets, hipMemcpyDeviceToHost, s));
-    if (out_samples) HIP_TRY(ctx, hipMemcpyAsync(out_samples, d_os, sizeof(int32_t) * n_packets, hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipStreamSynchronize(s));
+    const size_t pitch = sizeof(int32_t) * (size_t)slot_ints;
+    const size_t packed_w = std::min(pitch, packed_bytes_per_slot_int(ctx) * (size_t)slot_ints);
+    for (int k = 0; k < nch; k++) {
+        hipStream_t s = ctx->streams[k];
+        const uint32_t cnt = lo[k + 1] - lo[k];
+        if (cnt == 0) continue;
+        int32_t* dst = pcm_out + (size_t)lo[k] * slot_ints;
+        const int32_t* src = d_pcm + (size_t)lo[k] * slot_ints;
+        if (ctx->out_format == ALACGPU_OUT_PACKED_LE) {
+            // a slot holds at most slot_ints samples of (ctor sample size / 8) bytes: copy that much of every slot
+            HIP_TRY(ctx, hipMemcpy2DAsync(dst, pitch, src, pitch, packed_w, cnt, hipMemcpyDeviceToHost, s));
+        } else {
+            HIP_TRY(ctx, hipMemcpyAsync(dst, src, pitch * cnt, hipMemcpyDeviceToHost, s));
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(status + lo[k], d_st + lo[k], sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, s));
+        if (out_bytes) HIP_TRY(ctx, hipMemcpyAsync(out_bytes + lo[k], d_ob + lo[k], sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, s));
+        if (out_samples) HIP_TRY(ctx, hipMemcpyAsync(out_samples + lo[k], d_os + lo[k], sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, s));
+    }
+    for (int k = 0; k < nch; k++) HIP_TRY(ctx, hipStreamSynchronize(ctx->streams[k]));
     return ALACGPU_OK;
 }
 
@@ -397,8 +451,11 @@ int alacgpu_decode_frame(alacgpu_ctx* ctx, uint32_t cfg_index, const uint8_t* in
     if (!ctx || !inbuffer || !outbuffer || !status || cfg_index >= ctx->n_cfgs) return ALACGPU_ERR_BAD_ARG;
     const alacgpu_cfg& cfg = ctx->h_cfgs[cfg_index];
     const uint32_t slot = 16384u * cfg.num_channels;
-    int32_t* pcm = (int32_t*)std::malloc(sizeof(int32_t) * slot);
-    if (!pcm) return ALACGPU_ERR_NO_MEMORY;
+    if (!ctx->h_frame) {   // pinned, sized for the widest case once (16384 samples x 2 channels)
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_frame, sizeof(int32_t) * 16384u * 2u, hipHostMallocDefault));
+    }
+    int32_t* pcm = ctx->h_frame;
     const uint64_t off = 0;
     const uint16_t ci = (uint16_t)cfg_index;
     int32_t ob = 0, os = 0, st = 0;
@@ -415,7 +472,6 @@ int alacgpu_decode_frame(alacgpu_ctx* ctx, uint32_t cfg_index, const uint8_t* in
             else alacgpu_expand_reference_layout(&cfg, pcm, os, outbuffer);
         }
     }
-    std::free(pcm);
     return rc;
 }
 
@@ -425,17 +481,12 @@ int alacgpu_set_output_format(alacgpu_ctx* ctx, int format) {
     return ALACGPU_OK;
 }
 
-int alacgpu_set_kernel_variant(alacgpu_ctx* ctx, int variant) {
-    if (!ctx || variant < 0 || variant > 5) return ALACGPU_ERR_BAD_ARG;
-    ctx->variant = variant;
-    return ALACGPU_OK;
-}
-
 float alacgpu_last_kernel_ms(alacgpu_ctx* ctx) {
-    if (!ctx || !ctx->timed) return -1.0f;
-    if (hipEventSynchronize(ctx->ev1) != hipSuccess) return -1.0f;
+    if (!ctx || ctx->last_slot < 0) return -1.0f;
+    launch_slot& sl = ctx->slots[ctx->last_slot];
+    if (hipEventSynchronize(sl.ev1) != hipSuccess) return -1.0f;
     float ms = -1.0f;
-    if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) != hipSuccess) return -1.0f;
+    if (hipEventElapsedTime(&ms, sl.ev0, sl.ev1) != hipSuccess) return -1.0f;
     return ms;
 }
 

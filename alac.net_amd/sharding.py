@@ -44,3 +44,46 @@ def allgather_pcm(local_pcm, n_packets, group=None):
         lo, hi = shard_range(n_packets, r, world)
         parts.append(out[r * per: r * per + (hi - lo)])
     return torch.cat(parts, dim=0)
+
+
+class ChunkedDecodeAllGather:
+    """Decode + all-gather of one rank's shard, overlapped: the shard is decoded in `n_chunks` contiguous packet ranges
+    and the all-gather of range k runs (on the collective's own stream) while range k+1 decodes.
+
+    `local_pcm`: this rank's [per_rank, slot] PCM tensor on the GPU (the decode writes into it).  With a CUDA-aware
+    backend (nccl = RCCL over xGMI) the operands stay in HBM; otherwise (gloo rehearsal) every range goes through the
+    host.  `run(decode_range)` calls decode_range(lo, hi) for every range -- which must enqueue the decode of packets
+    [lo, hi) of the shard on torch's current stream -- and returns the gathered [world * per_rank, slot] tensor in
+    global packet order (rank r's packets at [r * per_rank, (r + 1) * per_rank)).
+
+    RCCL picks the all-gather algorithm itself; with equal-size shards of 32 MiB and more per range it is bandwidth
+    bound on the 7 xGMI links of every GPU.  No collective touches the decode itself."""
+
+    def __init__(self, local_pcm, world, n_chunks=4, cuda_collective=True, group=None):
+        import torch
+
+        self.local, self.world, self.group, self.cuda = local_pcm, world, group, cuda_collective
+        per = local_pcm.shape[0]
+        n_chunks = max(1, min(n_chunks, per))
+        self.bounds = [(per * k // n_chunks, per * (k + 1) // n_chunks) for k in range(n_chunks)]
+        cdev = local_pcm.device if cuda_collective else torch.device("cpu")
+        tail = tuple(local_pcm.shape[1:])
+        self.full = torch.empty((world * per,) + tail, dtype=local_pcm.dtype, device=cdev)
+        self.stage = [torch.empty((world * (hi - lo),) + tail, dtype=local_pcm.dtype, device=cdev) for lo, hi in self.bounds]
+
+    def run(self, decode_range):
+        import torch.distributed as dist
+
+        per = self.local.shape[0]
+        works = []
+        for k, (lo, hi) in enumerate(self.bounds):
+            decode_range(lo, hi)
+            src = self.local[lo:hi] if self.cuda else self.local[lo:hi].cpu()
+            # the collective starts once the current stream has reached this point, i.e. after range k's decode; the
+            # current stream itself goes on with range k+1
+            works.append(dist.all_gather_into_tensor(self.stage[k], src.contiguous(), group=self.group, async_op=True))
+        fv = self.full.view((self.world, per) + tuple(self.full.shape[1:]))
+        for k, (lo, hi) in enumerate(self.bounds):
+            works[k].wait()
+            fv[:, lo:hi].copy_(self.stage[k].view((self.world, hi - lo) + tuple(self.full.shape[1:])))
+        return self.full

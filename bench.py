@@ -1,18 +1,27 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json's metric: decoded PCM Msamples/s on batched frames.
 
-A "step" is one pass of the hot path (alac_decode_packets_kernel through the C ABI's
+A "step" is one pass of the hot path (alac_decode_ab_kernel + alac_decode_ab32_kernel through the C ABI's
 alacgpu_decode_batch_device) over one batch of synthetic packets already resident in HBM.
-N=1 workload = BASELINE configs[1]: 4 096 synthetic 16-bit stereo packets, 4096 samples/frame,
-LPC order 8.  N>1: one process per GPU, every rank decodes its own 4 096-packet shard
-(weak scaling, no data-path collective inside the timed region); the decoded-PCM all-gather
-north_star names is run and timed separately after the timed region (`allgather_ms`).
+Workload of `value` at every N = BASELINE configs[1] ("cfg2"): 4 096 synthetic 16-bit stereo packets per GPU,
+4096 samples/frame, LPC order 8.  N>1: one process per GPU, every rank decodes its own shard (weak scaling, no data-path
+collective inside the timed region).  At N>1 the two multi-GPU configs of BASELINE.json are measured as well and
+reported under "extra_configs": cfg4 (16-bit mono, 8 192 packets per GPU) and cfg5 (mixed LPC order / bit depth,
+4 096 packets per GPU), each with the decoded-PCM all-gather north_star names -- alone (`allgather_ms`) and overlapped
+with the decode chunk by chunk (`decode_allgather_overlapped_ms`).
+
+`python bench.py --gpus N` without a launcher starts the N ranks itself (torch.distributed.run as a child process,
+before anything in this process touches the GPU) and relays rank 0's JSON line and the children's exit code.
+Exit code: 0 only if every rank decoded with status OK and (N=1) the whole batch equals the oracle's output.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,38 +30,220 @@ for _p in (ROOT, os.path.join(ROOT, "oracle")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
-import numpy as np
-import torch
-
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+PER_GPU_PACKETS = {2: 4096, 3: 8192, 4: 8192, 5: 4096}  # cfg4/cfg5 are quoted per 8 GPUs: 65536/8, 32768/8
+NAMES = {2: "cfg2: 4096 synthetic 16-bit stereo packets, 4096 samples/frame, LPC order 8",
+         3: "cfg3: 24-bit stereo, 8192-sample packets, LPC order 16",
+         4: "cfg4: 16-bit mono, 4096-sample packets",
+         5: "cfg5: mixed LPC order 4-31, mixed 16/24-bit"}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", type=int, default=2, help="BASELINE.json config number (2..5)")
+    ap.add_argument("--config", type=int, default=2, help="BASELINE.json config number (2..5) behind `value`")
     ap.add_argument("--packets", type=int, default=None, help="packets per GPU (default: the config's batch)")
-    ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 auto, 1 fused, 2/3/4 split, 5 two-pass)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="single-thread CPU baseline: run at least this long")
     ap.add_argument("--no-allgather", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="N>1: skip the cfg4 / cfg5 extra measurements")
+    ap.add_argument("--extra-packets", type=int, default=None, help="packets per GPU of the extra configs (rehearsals)")
+    ap.add_argument("--no-host-path", action="store_true", help="N=1: skip the PCIe-inclusive and latency measurements")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 path)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+# ------------------------------------------------------------------------------------------------------------------
+# self-launch: nothing in here may touch the GPU (a process that has initialised HIP must not start/replace programs
+# carelessly on this pool; the parent only counts devices through sysfs, spawns, waits and relays)
+# ------------------------------------------------------------------------------------------------------------------
+def _visible_gpu_count():
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None and v.strip() != "":
+            return len([x for x in v.split(",") if x.strip() != ""])
+    n = 0
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for node in os.listdir(base):
+            try:
+                props = open(os.path.join(base, node, "properties")).read()
+            except OSError:
+                continue
+            for line in props.splitlines():
+                if line.startswith("simd_count") and int(line.split()[1]) > 0:
+                    n += 1
+    except OSError:
+        return None   # no KFD: let the ranks report it
+    return n
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(args, argv):
+    ndev = _visible_gpu_count()
+    if not args.same_device and ndev is not None and ndev < args.gpus:
+        print(json.dumps({"error": f"--gpus {args.gpus} asked for, {ndev} GPU(s) visible", "n_gpus": args.gpus}), flush=True)
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL across processes needs it on this pool)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
+# ------------------------------------------------------------------------------------------------------------------
+class Workload:
+    """One rank's shard of a BASELINE config, resident in HBM, with its context."""
+
+    def __init__(self, pkg, synth, torch, np, cfgno, n_packets, rank, dev, local_rank):
+        self.np, self.torch = np, torch
+        t0 = time.time()
+        b = synth.make_config_batch(cfgno, n_packets=n_packets, first_index=rank * n_packets, want_pcm=False)
+        self.gen_s = time.time() - t0
+        self.b, self.cfgno, self.n_packets, self.dev = b, cfgno, n_packets, dev
+        self.slot = int(b["slot_ints"])
+        self.blob_bytes = int(b["blob"].size)
+        # device allocation readable up to align_up(blob_bytes, 16)
+        self.d_blob = torch.zeros((self.blob_bytes + 63) // 16 * 16 + 64, dtype=torch.uint8, device=dev)
+        self.d_blob[:self.blob_bytes] = torch.from_numpy(b["blob"]).to(dev)
+        self.d_off = torch.from_numpy(b["offsets"].astype(np.int64)).to(dev)  # same bits as uint64
+        self.d_sz = torch.from_numpy(b["sizes"].astype(np.int32)).to(dev)     # same bits as uint32
+        self.d_ci = None if b["cfg_idx"] is None else torch.from_numpy(b["cfg_idx"].astype(np.int16)).to(dev)
+        self.d_pcm = torch.zeros((n_packets, self.slot), dtype=torch.int32, device=dev)
+        self.d_ob = torch.zeros(n_packets, dtype=torch.int32, device=dev)
+        self.d_os = torch.zeros(n_packets, dtype=torch.int32, device=dev)
+        self.d_st = torch.full((n_packets,), -1, dtype=torch.int32, device=dev)
+        self.ctx = pkg.AlacGpuContext(b["stream_cfgs"], device=local_rank)
+        descs = b["descs"]
+        nch = 1 + descs["stereo"].astype(np.int64)
+        self.nch = nch
+        self.samples = int((descs["n"].astype(np.int64) * nch).sum())          # S_ch = sum n*channels
+        ci = np.zeros(n_packets, dtype=int) if b["cfg_idx"] is None else b["cfg_idx"].astype(int)
+        out_nc = np.array([b["stream_cfgs"][int(i)][5] for i in ci], dtype=np.int64)
+        self.algo_bytes = int(b["sizes"].astype(np.int64).sum() + (4 * descs["n"].astype(np.int64) * out_nc).sum())
+
+    def step(self, stream, lo=0, hi=None):
+        hi = self.n_packets if hi is None else hi
+        self.ctx.decode_batch_device(self.d_blob, self.blob_bytes, self.d_off[lo:hi], self.d_sz[lo:hi],
+                                     None if self.d_ci is None else self.d_ci[lo:hi], hi - lo, self.d_pcm[lo:hi], self.slot,
+                                     self.d_ob[lo:hi], self.d_os[lo:hi], self.d_st[lo:hi], stream=stream.cuda_stream)
+
+    def status_ok(self):
+        st = self.d_st.cpu().numpy()
+        return bool((st == 0).all()) if self.cfgno != 5 else bool((st >= 0).all() and (st == 0).mean() > 0.9)
+
+    def close(self):
+        self.ctx.close()
+
+
+def timed_steps(torch, dist, w, steps, warmup, dev, distributed):
+    """W untimed + EXACTLY K timed steps bracketed by barrier + synchronize on both sides; returns (seconds, kernel ms)."""
+    stream = torch.cuda.current_stream(dev)
+    for _ in range(warmup):
+        w.step(stream)
+    torch.cuda.synchronize(dev)
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for e0, e1 in evs:
+        e0.record(stream)      # the launch stream IS torch's current stream here
+        w.step(stream)
+        e1.record(stream)
+    torch.cuda.synchronize(dev)
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    kernel_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / len(evs)
+    return elapsed, float(kernel_ms)
+
+
+def reduce_max(torch, dist, cdev, *vals):
+    t = torch.tensor(list(vals), dtype=torch.float64, device=cdev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [float(x) for x in t.tolist()]
+
+
+def reduce_sum(torch, dist, cdev, *vals):
+    t = torch.tensor(list(vals), dtype=torch.int64, device=cdev)
+    dist.all_reduce(t)
+    return [int(x) for x in t.tolist()]
+
+
+def kernel_source_sha():
+    h = hashlib.sha256()
+    for fn in ("alac_kernels.hip", "alac_device.h", "alac_kernels.h"):
+        h.update(open(os.path.join(ROOT, "alac.net_amd", "csrc", fn), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def measure_allgather(torch, dist, sharding, w, world, rank, dev, backend, reps=3):
+    """(collective alone, decode + all-gather overlapped chunk by chunk), milliseconds; checks the gathered PCM."""
+    n = w.n_packets
+    cuda_coll = backend == "nccl"
+    src = w.d_pcm if cuda_coll else w.d_pcm.cpu()
+    gathered = sharding.allgather_pcm(src, world * n)
+    torch.cuda.synchronize(dev)
+    dist.barrier()
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        gathered = sharding.allgather_pcm(src, world * n)
+    torch.cuda.synchronize(dev)
+    alone_ms = (time.perf_counter() - t1) / reps * 1e3
+    ok = bool(torch.equal(gathered[rank * n:(rank + 1) * n], src))
+    del gathered
+    # overlapped: the shard decodes in chunks; chunk k's all-gather runs while chunk k+1 decodes
+    pipe = sharding.ChunkedDecodeAllGather(w.d_pcm, world, n_chunks=4, cuda_collective=cuda_coll)
+    stream = torch.cuda.current_stream(dev)
+    full = pipe.run(lambda lo, hi: w.step(stream, lo, hi))
+    torch.cuda.synchronize(dev)
+    dist.barrier()
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        full = pipe.run(lambda lo, hi: w.step(stream, lo, hi))
+    torch.cuda.synchronize(dev)
+    over_ms = (time.perf_counter() - t1) / reps * 1e3
+    ok = ok and bool(torch.equal(full[rank * n:(rank + 1) * n], src))
+    del full, pipe
+    return alone_ms, over_ms, ok
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1 and args.gpus > 1:
+        sys.exit(spawn_ranks(args, argv))   # the children are the ranks; this process never touches the GPU
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = 0 if args.same_device else int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
-    if args.same_device:
-        local_rank = 0
+    ndev = torch.cuda.device_count()       # (does not initialise the GPU)
+    if ndev <= local_rank:
+        if rank == 0:
+            print(json.dumps({"error": f"rank needs cuda:{local_rank}, {ndev} device(s) visible", "n_gpus": world}), flush=True)
+        raise SystemExit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     cdev = dev if args.backend == "nccl" else torch.device("cpu")   # where collective operands live
+    dist = None
     if distributed:
         import torch.distributed as dist
 
@@ -63,173 +254,190 @@ def main():
             dist.init_process_group(args.backend)
 
     import alac.net_amd as pkg
-    from alac.net_amd import synth
+    from alac.net_amd import sharding, synth
 
-    per_gpu_default = {2: 4096, 3: 8192, 4: 8192, 5: 4096}  # cfg4/cfg5 are quoted per 8 GPUs: 65536/8, 32768/8
-    n_packets = args.packets or per_gpu_default[args.config]
-
-    # ---- synthetic input for this rank's shard (seeded by global packet index) ----
-    t0 = time.time()
-    b = synth.make_config_batch(args.config, n_packets=n_packets, first_index=rank * n_packets, want_pcm=False)
-    gen_s = time.time() - t0
-    descs = b["descs"]
-    slot = int(b["slot_ints"])
-    blob_np = b["blob"]
-    blob_bytes = int(blob_np.size)
-    # device allocation readable up to align_up(blob_bytes, 16)
-    d_blob = torch.zeros((blob_bytes + 63) // 16 * 16 + 64, dtype=torch.uint8, device=dev)
-    d_blob[:blob_bytes] = torch.from_numpy(blob_np).to(dev)
-    d_off = torch.from_numpy(b["offsets"].astype(np.int64)).to(dev)  # same bits as uint64
-    d_sz = torch.from_numpy(b["sizes"].astype(np.int32)).to(dev)     # same bits as uint32
-    d_ci = None
-    if b["cfg_idx"] is not None:
-        d_ci = torch.from_numpy(b["cfg_idx"].astype(np.int16)).to(dev)
-    d_pcm = torch.zeros((n_packets, slot), dtype=torch.int32, device=dev)
-    d_ob = torch.zeros(n_packets, dtype=torch.int32, device=dev)
-    d_os = torch.zeros(n_packets, dtype=torch.int32, device=dev)
-    d_st = torch.full((n_packets,), -1, dtype=torch.int32, device=dev)
-
-    ctx = pkg.AlacGpuContext(b["stream_cfgs"], device=local_rank)
-    ctx.set_kernel_variant(args.variant)
-    stream = torch.cuda.current_stream(dev)
-
-    def step():
-        ctx.decode_batch_device(d_blob, blob_bytes, d_off, d_sz, d_ci, n_packets, d_pcm, slot, d_ob, d_os, d_st,
-                                stream=stream.cuda_stream)
-
-    nch = 1 + descs["stereo"].astype(np.int64)
-    samples_per_step = int((descs["n"].astype(np.int64) * nch).sum())          # S_ch = sum n*channels
-    out_nc = np.array([b["stream_cfgs"][0 if b["cfg_idx"] is None else int(i)][5] for i in
-                       (np.zeros(n_packets, dtype=int) if b["cfg_idx"] is None else b["cfg_idx"])], dtype=np.int64)
-    algo_bytes = int(b["sizes"].astype(np.int64).sum() + (4 * descs["n"].astype(np.int64) * out_nc).sum())
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize(dev)
+    n_packets = args.packets or PER_GPU_PACKETS[args.config]
+    w = Workload(pkg, synth, torch, np, args.config, n_packets, rank, dev, local_rank)
+    elapsed, kernel_ms = timed_steps(torch, dist, w, args.steps, args.warmup, dev, distributed)
+    status_ok = w.status_ok()
+    total_samples = w.samples
     if distributed:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for e0, e1 in evs:
-        e0.record(stream)
-        step()
-        e1.record(stream)
-    torch.cuda.synchronize(dev)
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in evs]))
+        elapsed, kernel_ms = reduce_max(torch, dist, cdev, elapsed, kernel_ms)
+        total_samples, bad = reduce_sum(torch, dist, cdev, w.samples, 0 if status_ok else 1)
+        status_ok = bad == 0
 
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        k = torch.tensor([kernel_ms], dtype=torch.float64, device=cdev)
-        dist.all_reduce(k, op=dist.ReduceOp.MAX)
-        kernel_ms = float(k.item())
-        tot = torch.tensor([samples_per_step, algo_bytes], dtype=torch.int64, device=cdev)
-        dist.all_reduce(tot)
-        total_samples_per_step = int(tot[0].item())
-    else:
-        total_samples_per_step = samples_per_step
-
-    # ---- decoded-PCM all-gather over RCCL/xGMI (outside the timed region; reported separately) ----
-    allgather_ms = None
+    # ---- N>1: decoded-PCM all-gather (outside the timed region) and the two multi-GPU configs of BASELINE.json ----
+    allgather_ms = overlapped_ms = None
+    gather_ok = True
+    extra = {}
     if distributed and not args.no_allgather:
-        from alac.net_amd import sharding
-
-        src = d_pcm if args.backend == "nccl" else d_pcm.cpu()
-        gathered = sharding.allgather_pcm(src, world * n_packets)
-        torch.cuda.synchronize(dev)
-        dist.barrier()
-        t1 = time.perf_counter()
-        reps = 3
-        for _ in range(reps):
-            gathered = sharding.allgather_pcm(src, world * n_packets)
-        torch.cuda.synchronize(dev)
-        allgather_ms = (time.perf_counter() - t1) / reps * 1e3
-        assert torch.equal(gathered[rank * n_packets:(rank + 1) * n_packets], src)
-        del gathered
+        allgather_ms, overlapped_ms, gather_ok = measure_allgather(torch, dist, sharding, w, world, rank, dev, args.backend)
+    if distributed and not args.no_extra:
+        for cfgno in (4, 5):
+            if cfgno == args.config:
+                continue
+            npk = args.extra_packets or PER_GPU_PACKETS[cfgno]
+            we = Workload(pkg, synth, torch, np, cfgno, npk, rank, dev, local_rank)
+            ksteps = max(1, min(args.steps, 10))
+            el, kms = timed_steps(torch, dist, we, ksteps, min(args.warmup, 2), dev, True)
+            ok = we.status_ok()
+            el, kms = reduce_max(torch, dist, cdev, el, kms)
+            tot, ab, bad = reduce_sum(torch, dist, cdev, we.samples, we.algo_bytes, 0 if ok else 1)
+            row = {"workload": NAMES[cfgno], "packets_per_gpu": npk, "steps": ksteps,
+                   "value": round(tot * ksteps / el / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(el / ksteps * 1e3, 4),
+                   "kernel_ms": round(kms, 4), "roofline_frac": round(we.algo_bytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                   "status_ok": bad == 0}
+            if not args.no_allgather:
+                a_ms, o_ms, g_ok = measure_allgather(torch, dist, sharding, we, world, rank, dev, args.backend)
+                a_ms, o_ms = reduce_max(torch, dist, cdev, a_ms, o_ms)
+                row.update(allgather_ms=round(a_ms, 4), decode_allgather_overlapped_ms=round(o_ms, 4),
+                           allgather_bytes_per_rank=int(we.d_pcm.numel() * 4))
+                gather_ok = gather_ok and g_ok
+            status_ok = status_ok and bad == 0
+            extra[f"cfg{cfgno}"] = row
+            we.close()
+            del we
+    if distributed:
+        (gbad,) = reduce_sum(torch, dist, cdev, 0 if gather_ok else 1)
+        gather_ok = gbad == 0
+        if allgather_ms is not None:
+            allgather_ms, overlapped_ms = reduce_max(torch, dist, cdev, allgather_ms, overlapped_ms)
 
     # ---- correctness + CPU baseline (rank 0, N=1 only; the oracle is the checker, never the product) ----
-    st = d_st.cpu().numpy()
-    status_ok = bool((st == 0).all()) if args.config != 5 else bool((st >= 0).all())
+    b = w.b
     cpu_baseline = None
     parity = None
+    host_path = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import alac_oracle_py as orc
 
         cfgs = orc.make_cfgs(b["stream_cfgs"])
-        ncores = len(os.sched_getaffinity(0))
-        # bounded sample: the first `take` packets of the same batch, one thread
-        take = min(n_packets, 2048)
-        sub_samples = int((descs["n"][:take].astype(np.int64) * nch[:take]).sum())
+        allcores = sorted(os.sched_getaffinity(0))
+        ncores = len(allcores)
+        # whole batch on all cores: the parity reference
         t1 = time.perf_counter()
-        ref = orc.decode_batch(cfgs, blob_np, b["offsets"][:take], b["sizes"][:take],
-                               None if b["cfg_idx"] is None else b["cfg_idx"][:take], slot, n_threads=1)
-        cpu1_s = time.perf_counter() - t1
-        t1 = time.perf_counter()
-        refall = orc.decode_batch(cfgs, blob_np, b["offsets"], b["sizes"], b["cfg_idx"], slot, n_threads=ncores)
+        refall = orc.decode_batch(cfgs, b["blob"], b["offsets"], b["sizes"], b["cfg_idx"], w.slot, n_threads=ncores)
         cpuall_s = time.perf_counter() - t1
-        got = d_pcm.cpu().numpy()
+        got = w.d_pcm.cpu().numpy()
+        st = w.d_st.cpu().numpy()
         okm = refall[3] == 0
         parity = bool(np.array_equal(st, refall[3]) and np.array_equal(got[okm], refall[0][okm])
-                      and np.array_equal(d_ob.cpu().numpy(), refall[1]))
+                      and np.array_equal(w.d_ob.cpu().numpy(), refall[1]))
+        # single thread, pinned to one core, the same batch over and over for >= --cpu-seconds
+        os.sched_setaffinity(0, {allcores[len(allcores) // 2]})
+        try:
+            reps, t1 = 0, time.perf_counter()
+            while True:
+                orc.decode_batch(cfgs, b["blob"], b["offsets"], b["sizes"], b["cfg_idx"], w.slot, n_threads=1)
+                reps += 1
+                cpu1_s = time.perf_counter() - t1
+                if cpu1_s >= args.cpu_seconds:
+                    break
+        finally:
+            os.sched_setaffinity(0, set(allcores))
         cpu_baseline = {
-            "value": round(sub_samples / cpu1_s / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
-            "sample": f"first {take} packets of the same batch, C restatement of AlacFile.DecodeFrame "
-                      f"(C# runtime unavailable), 1 thread",
-            "all_cores_value": round(samples_per_step / cpuall_s / 1e6, 3), "all_cores": ncores,
+            "value": round(w.samples * reps / cpu1_s / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": f"the same {n_packets}-packet batch decoded {reps} times ({cpu1_s:.1f} s) by the C restatement of "
+                      f"AlacFile.DecodeFrame (oracle/alac_oracle.c; C# runtime unavailable), 1 thread pinned to one core",
+            "all_cores_value": round(w.samples / cpuall_s / 1e6, 3), "all_cores": ncores,
         }
+    if rank == 0 and world == 1 and not args.no_host_path:
+        host_path = measure_host_path(pkg, np, w)
 
     if rank == 0:
-        all_mono = all(c[5] == 1 for c in b["stream_cfgs"])
-        split_auto = 4 if n_packets > (10240 if all_mono else 5120) else 3
-        auto = 4 if (all_mono and 10240 < n_packets <= 20480) else 5   # mirrors the library's choice (alacgpu_api.hip: launch)
-        kernel_name = {1: "alac_decode_packets_kernel", 2: "alac_decode_split1_kernel", 3: "alac_decode_split2_kernel",
-                       4: "alac_decode_split4_kernel", 5: "alac_decode_ab_kernel"}[args.variant or auto]
-        if all_mono and (args.variant or auto) in (3, 4):
-            kernel_name = kernel_name.replace("_kernel", "_mono_kernel")
-        if (args.variant or auto) == 5 and args.config == 5:
+        kernel_name = "alac_decode_ab_kernel"
+        if args.config == 5:
             # LPC orders above 16 in (nearly) every group of 8 packets: the work is done by the 32-tap arrangement launched
             # behind the main two-pass kernel
             kernel_name = "alac_decode_ab32_kernel (behind alac_decode_ab_kernel)"
-        # HBM traffic comes from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read in-process):
-        # the committed measurement of the same workload + kernel, see profiles/
-        traffic = None
+        # HBM traffic comes from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read in-process): the committed
+        # measurement of the same workload, valid only for the kernel sources it was taken with
+        traffic, traffic_note = None, None
         tfile = os.path.join(ROOT, "profiles", f"traffic_cfg{args.config}.json")
         if os.path.exists(tfile) and args.packets is None:
             tj = json.load(open(tfile))
-            if tj.get("kernel") == kernel_name:
+            if tj.get("kernel_source_sha") == kernel_source_sha():
                 traffic = tj["hbm_bytes_per_launch"]
+            else:
+                traffic_note = "profiles/traffic_cfg%d.json was measured with other kernel sources (stale): not reported" % args.config
         ms_per_step = elapsed / args.steps * 1e3
-        value = total_samples_per_step * args.steps / elapsed / 1e6
-        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
-        names = {2: "cfg2: 4096 synthetic 16-bit stereo packets, 4096 samples/frame, LPC order 8",
-                 3: "cfg3: 24-bit stereo, 8192-sample packets, LPC order 16",
-                 4: "cfg4: 16-bit mono, 4096-sample packets",
-                 5: "cfg5: mixed LPC order 4-31, mixed 16/24-bit"}
+        value = total_samples * args.steps / elapsed / 1e6
+        achieved = w.algo_bytes / (kernel_ms * 1e-3) / 1e9
         line = {
             "metric": "decoded PCM Msamples/sec (batched frames)", "value": round(value, 3), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
             "data": "synthetic",
-            "config": {"workload": names[args.config], "packets_per_gpu": n_packets,
-                       "samples_per_step_per_gpu": samples_per_step, "parallelism": f"packet-sharded x{world}"},
+            "config": {"workload": NAMES[args.config], "packets_per_gpu": n_packets,
+                       "samples_per_step_per_gpu": w.samples, "parallelism": f"packet-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "kernel": kernel_name, "kernel_ms": round(kernel_ms, 4),
-                         "algorithmic_bytes_per_launch": algo_bytes},
+                         "algorithmic_bytes_per_launch": w.algo_bytes},
             "cpu_baseline": cpu_baseline,
-            "parity_vs_oracle": parity, "status_ok": status_ok, "allgather_ms": allgather_ms,
-            "gen_seconds": round(gen_s, 2),
+            "parity_vs_oracle": parity, "status_ok": status_ok,
+            "allgather_ms": None if allgather_ms is None else round(allgather_ms, 4),
+            "decode_allgather_overlapped_ms": None if overlapped_ms is None else round(overlapped_ms, 4),
+            "allgather_ok": gather_ok if distributed else None,
+            "gen_seconds": round(w.gen_s, 2),
         }
+        if traffic_note:
+            line["roofline"]["traffic_note"] = traffic_note
+        if extra:
+            line["extra_configs"] = extra
+        if host_path:
+            line["host_path"] = host_path
         print(json.dumps(line), flush=True)
-    ctx.close()
+    w.close()
     if distributed:
         dist.destroy_process_group()
+    if not status_ok or parity is False or not gather_ok:
+        raise SystemExit(1)
+
+
+def measure_host_path(pkg, np, w):
+    """PCIe-inclusive figures (never `value`): alacgpu_decode_batch on host buffers -- upload, decode and download
+    overlapped range by range -- with reused pinned buffers and with ordinary (pageable) ones; and the latency of small
+    calls (alacgpu_decode_frame = one packet; batches of 1 / 8 / 64)."""
+    b = w.b
+    n = w.n_packets
+    out = {}
+    ctx = w.ctx
+
+    def bench(fn, reps):
+        fn()
+        t = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        return (time.perf_counter() - t) / reps * 1e3
+
+    with pkg.PinnedBuffer((n, w.slot), np.int32) as ppcm, pkg.PinnedBuffer(b["blob"].size, np.uint8) as pblob:
+        pblob.array[:] = b["blob"]
+        for fmt, name in ((0, "int32"), (1, "packed")):
+            ctx.set_output_format(fmt)
+            ms = bench(lambda: ctx.decode_batch(pblob.array, b["offsets"], b["sizes"], b["cfg_idx"], w.slot, out=ppcm.array), 5)
+            out[f"{name}_pinned_ms"] = round(ms, 3)
+            out[f"{name}_pinned_msamples_per_s"] = round(w.samples / ms / 1e3, 1)
+        pcm = np.zeros((n, w.slot), dtype=np.int32)
+        for fmt, name in ((0, "int32"), (1, "packed")):
+            ctx.set_output_format(fmt)
+            ms = bench(lambda: ctx.decode_batch(b["blob"], b["offsets"], b["sizes"], b["cfg_idx"], w.slot, out=pcm), 5)
+            out[f"{name}_pageable_ms"] = round(ms, 3)
+        ctx.set_output_format(0)
+    # small calls
+    o0, s0 = int(b["offsets"][0]), int(b["sizes"][0])
+    pkt = b["blob"][o0:o0 + s0].copy()
+    ci0 = 0 if b["cfg_idx"] is None else int(b["cfg_idx"][0])
+    out["decode_frame_ms"] = round(bench(lambda: ctx.decode_frame(ci0, pkt), 20), 4)
+    for k in (1, 8, 64):
+        if k > n:
+            break
+        sl = np.zeros((k, w.slot), dtype=np.int32)
+        ci = None if b["cfg_idx"] is None else b["cfg_idx"][:k]
+        out[f"batch{k}_ms"] = round(bench(lambda: ctx.decode_batch(b["blob"], b["offsets"][:k], b["sizes"][:k], ci, w.slot, out=sl), 20), 4)
+    out["note"] = ("host buffers in, host buffers out (PCIe inclusive); decode_frame_ms = one packet through "
+                   "alacgpu_decode_frame; a serial chain of 2 x n symbols bounds a lone packet at about 0.7 ms")
+    return out
 
 
 if __name__ == "__main__":

@@ -7,7 +7,10 @@
  *     AlacContext.cs:197     var outputBytes = _alac.DecodeFrame(_readBuffer, pDestBuffer);
  * and each entry point below names the reference member it replaces.  A C# host binds these with
  * [DllImport("alacgpu")].  Plain pointers and sizes only; caller allocates
- * everything; the library never keeps a caller pointer past the call; one ctx per host thread.
+ * everything; the library never keeps a caller pointer past the call; one ctx per host thread
+ * (a ctx is not thread-safe; one thread may keep up to 8 asynchronous device-pointer calls in flight on
+ * any streams, see alacgpu_decode_batch_device).  One ctx drives one GPU: a multi-GPU host creates one ctx
+ * per device (alacgpu_device_count) -- in this repository one process per GPU (bench.py, sharding.py).
  *
  * Return codes: 0 = the batch ran (inspect status[]), < 0 = batch-level failure.
  * There is NO CPU fallback: if no gfx950 device / kernel image is usable, create fails.
@@ -22,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ALACGPU_VERSION 1
+#define ALACGPU_VERSION 2
 
 /* Stream configuration = the AlacFile ctor args + what AlacFile.SetInfo keeps
  * (AlacFile.cs:16-20 and :63-93; CodecData byte offsets in brackets). 12 bytes, blittable. */
@@ -63,6 +66,9 @@ typedef struct alacgpu_ctx alacgpu_ctx;
 
 int alacgpu_version(void);
 
+/* Number of usable (gfx950) devices; 0 when there is none (then alacgpu_create fails: no CPU fallback). */
+int alacgpu_device_count(void);
+
 /* Replaces `new AlacFile(samplesize, numchannels)` + `SetInfo(codecData)` (AlacContext.cs:54-55)
  * for one or more streams at once (a batch may mix streams through cfg_idx[]).
  * device = HIP device ordinal. */
@@ -76,6 +82,11 @@ int alacgpu_cfg_from_codec_data(const int32_t* codec_data_ints, uint32_t n_ints,
 
 /*
  * Batched AlacFile.DecodeFrame (AlacFile.cs:428-719) on HOST buffers: H2D, decode kernel, D2H; blocking.
+ * Batches of 512 packets and more are cut into 2 or 4 contiguous packet ranges on separate streams so that the
+ * upload of one range, the decode of the previous and the download of the one before overlap (fastest when the
+ * packets lie in the blob in batch order and the buffers come from alacgpu_alloc_pinned; any layout works).
+ * Bytes outside [offsets[p], offsets[p]+sizes[p]) are never interpreted as part of packet p: a packet that is cut
+ * short decodes as if zero bits followed (and reports ALACGPU_ST_OVERRUN).
  *   blob/blob_bytes      concatenated raw ALAC packets
  *   offsets[p], sizes[p] packet p = blob[offsets[p] .. offsets[p]+sizes[p])   (any byte alignment)
  *   cfg_idx[p]           stream cfg of packet p; NULL = all 0
@@ -96,7 +107,10 @@ int alacgpu_decode_batch(alacgpu_ctx* ctx, const uint8_t* blob, uint64_t blob_by
 /*
  * Same, on DEVICE buffers already resident in HBM (all pointers are device pointers), asynchronous on
  * `hip_stream` (a hipStream_t; NULL = default stream).  d_blob must be 16-byte aligned and readable up to
- * blob_bytes rounded up to 16.  Outputs as above; d_out_bytes / d_out_samples may be NULL.
+ * blob_bytes rounded up to 16 (ALACGPU_ERR_BAD_ARG otherwise; the other arrays need their natural alignment).
+ * Outputs as above; d_out_bytes / d_out_samples may be NULL.  Up to 8 calls may be in flight at once on one ctx, on
+ * the same or on different streams (each owns its scratch until it has finished; a ninth call waits for the oldest).
+ * The caller keeps every buffer alive and unchanged until the stream has passed the call.
  */
 int alacgpu_decode_batch_device(alacgpu_ctx* ctx, const void* d_blob, uint64_t blob_bytes, const void* d_offsets,
                                 const void* d_sizes, const void* d_cfg_idx, uint32_t n_packets, void* d_pcm_out,
@@ -117,8 +131,9 @@ size_t alacgpu_expand_reference_layout(const alacgpu_cfg* cfg, const int32_t* pc
 /* AlacContext.FormatSamples (AlacContext.cs:214-256): reference int[] -> little-endian PCM bytes. */
 size_t alacgpu_format_samples(int bytes_per_sample, const int32_t* ref_ints, int32_t count_bytes, uint8_t* dst);
 
-/* Average kernel time of the last alacgpu_decode_batch* call's launch, from HIP events recorded
- * on the launch stream (milliseconds; < 0 if unavailable).  Synchronises the stream. */
+/* Kernel time of the most recent launch of this ctx, from HIP events recorded on the launch stream around it
+ * (milliseconds; < 0 if unavailable).  Waits for that launch.  After a host-buffer call that was cut into ranges
+ * this is the last range's launch. */
 float alacgpu_last_kernel_ms(alacgpu_ctx* ctx);
 
 /* Output layout of the batch entry points.  ALACGPU_OUT_INT32 (default): one int32 per sample, as documented
@@ -130,12 +145,10 @@ float alacgpu_last_kernel_ms(alacgpu_ctx* ctx);
 enum { ALACGPU_OUT_INT32 = 0, ALACGPU_OUT_PACKED_LE = 1 };
 int alacgpu_set_output_format(alacgpu_ctx* ctx, int format);
 
-/* Tuning / A-B knob (no effect on results): 0 = auto (default), 1 = fused single-wave kernel,
- * 2 / 3 / 4 = split kernel with 1 / 2 / 4 reconstruction waves per workgroup, 5 = two-pass kernels (channel A, then
- * channel B: no Rice pre-scan; LPC orders up to 16, then everything else in a second launch).  Auto is 5, except 4 for
- * one-channel cfgs in batches of 10241 to 20480 packets.  Also settable with
- * the environment variable ALACGPU_KERNEL_VARIANT at create time. */
-int alacgpu_set_kernel_variant(alacgpu_ctx* ctx, int variant);
+/* Page-locked host memory for batch buffers (blob, offsets, pcm_out ...): transfers from and to it run at link
+ * speed and asynchronously.  Optional -- every entry point takes ordinary memory too.  NULL on failure. */
+void* alacgpu_alloc_pinned(size_t bytes);
+void alacgpu_free_pinned(void* p);
 
 const char* alacgpu_strerror(int rc);
 const char* alacgpu_status_string(int status);

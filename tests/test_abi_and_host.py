@@ -25,7 +25,7 @@ def test_header_symbols_are_exported_and_bound():
     for n in names:
         assert hasattr(L, n), f"libalacgpu.so does not export {n}"
         assert n in pkg.SYMBOLS, f"python binding table misses {n}"
-    assert L.alacgpu_version() == 1
+    assert L.alacgpu_version() == 2
 
 
 def test_cfg_struct_layout_matches_header():

@@ -37,6 +37,19 @@ def _worker(rank, world, port, n_packets, outdir):
     local[: hi - lo] = torch.from_numpy(pcm)
     full = sharding.allgather_pcm(local, n_packets)
     assert full.shape == (n_packets, b["slot_ints"])
+    # the chunk-overlapped pipeline bench.py uses at N>1 (decode range by range, gather each range behind it)
+    local2 = torch.zeros_like(local)
+
+    def decode_range(l, h):          # stand-in decode of packets [l, h) of this rank's shard
+        h2 = min(h, hi - lo)
+        if l < h2:
+            local2[l:h2] = torch.from_numpy(pcm[l:h2])
+
+    pipe = sharding.ChunkedDecodeAllGather(local2, world, n_chunks=3, cuda_collective=False)
+    full2 = pipe.run(decode_range)
+    parts = [full2[r * per: r * per + (sharding.shard_range(n_packets, r, world)[1] - sharding.shard_range(n_packets, r, world)[0])]
+             for r in range(world)]
+    assert torch.equal(torch.cat(parts, dim=0), full)
     if rank == 0:
         ref = orc.decode_batch(orc.make_cfgs(b["stream_cfgs"]), b["blob"], b["offsets"], b["sizes"], b["cfg_idx"],
                                b["slot_ints"])[0]

@@ -19,12 +19,8 @@ def pkg():
     return p
 
 
-VARIANTS = [1, 2, 3, 4, 5]
-
-
-def run_both(pkg, oracle, b, n_threads=8, variant=0):
+def run_both(pkg, oracle, b, n_threads=8):
     with pkg.AlacGpuContext(b["stream_cfgs"], device=0) as ctx:
-        ctx.set_kernel_variant(variant)
         g = ctx.decode_batch(b["blob"], b["offsets"], b["sizes"], b["cfg_idx"], b["slot_ints"])
     o = oracle.decode_batch(oracle.make_cfgs(b["stream_cfgs"]), b["blob"], b["offsets"], b["sizes"], b["cfg_idx"],
                             b["slot_ints"], n_threads=n_threads)
@@ -47,11 +43,10 @@ def assert_same(g, o, cfgs=None, cfg_idx=None):
                                  f"gpu {gp[p, bad[:8]]} oracle {op[p, bad[:8]]}")
 
 
-@pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("cfg,n", [(2, 64), (3, 24), (4, 64), (5, 256)])
-def test_baseline_configs_small(pkg, oracle, synth, cfg, n, variant):
+def test_baseline_configs_small(pkg, oracle, synth, cfg, n):
     b = synth.make_config_batch(cfg, n_packets=n, want_pcm=True)
-    g, o = run_both(pkg, oracle, b, variant=variant)
+    g, o = run_both(pkg, oracle, b)
     assert_same(g, o, b["stream_cfgs"], b["cfg_idx"])
     # and both equal the encoder's source PCM (independent round trip)
     d = b["descs"]
@@ -66,11 +61,9 @@ def test_baseline_configs_small(pkg, oracle, synth, cfg, n, variant):
                 assert np.array_equal(got, src), f"packet {p} != source PCM"
 
 
-@pytest.mark.parametrize("variant", VARIANTS)
-def test_hand_kats_on_gpu(pkg, variant):
+def test_hand_kats_on_gpu(pkg):
     # the same hand-derived vectors that pin the oracle (tests/test_oracle_kat.py), straight on the GPU
     with pkg.AlacGpuContext([(4096, 16, 40, 10, 14, 2), (4096, 16, 40, 10, 14, 1), (4096, 24, 40, 10, 14, 2)]) as ctx:
-        ctx.set_kernel_variant(variant)
         k1 = pack([(3, 1), (4, 0), (12, 0), (1, 1), (2, 0), (1, 1), (32, 2), (16, 1), (16, 0xFFFF), (16, 0x7FFF), (16, 0x8000)])
         k2 = pack([(3, 0), (4, 0), (12, 0), (1, 1), (2, 0), (1, 0), (32, 3), (8, 0), (8, 0), (4, 0), (4, 0), (3, 4), (5, 0),
                    "110", "0", "10", "0"])
@@ -92,8 +85,7 @@ def test_hand_kats_on_gpu(pkg, variant):
         assert s == 0 and out_bytes == 6 and ref[:6].tolist() == [0xAB, 0x34, 0x12, 0xCD, 0, 0]
 
 
-@pytest.mark.parametrize("variant", VARIANTS)
-def test_unaligned_offsets_and_odd_batch(pkg, oracle, synth, variant):
+def test_unaligned_offsets_and_odd_batch(pkg, oracle, synth):
     b = synth.make_config_batch(2, n_packets=7, want_pcm=True)
     # re-pack the packets back to back at odd byte offsets
     parts, offs, pos = [], [], 3
@@ -105,13 +97,12 @@ def test_unaligned_offsets_and_odd_batch(pkg, oracle, synth, variant):
     b2 = dict(b)
     b2["blob"] = np.frombuffer(bytes(blob), dtype=np.uint8)
     b2["offsets"] = np.array(offs, dtype=np.uint64)
-    g, o = run_both(pkg, oracle, b2, variant=variant)
+    g, o = run_both(pkg, oracle, b2)
     assert_same(g, o, b["stream_cfgs"], None)
     assert np.array_equal(g[0], b["pcm"])
 
 
-@pytest.mark.parametrize("variant", VARIANTS)
-def test_statuses(pkg, oracle, synth, variant):
+def test_statuses(pkg, oracle, synth):
     d = synth.packet_descs(6, n=256, max_samples_per_frame=4096)
     d["channels_field"][0] = 2        # unsupported element
     d["pred_type"][1] = [0, 3]        # unhandled prediction type (stereo B)
@@ -122,7 +113,7 @@ def test_statuses(pkg, oracle, synth, variant):
     b.update(stream_cfgs=[(4096, 16, 40, 10, 14, 2)], cfg_idx=None)
     # truncate the last packet: bitstream overrun
     b["sizes"][5] = b["sizes"][5] // 2
-    g, o = run_both(pkg, oracle, b, variant=variant)
+    g, o = run_both(pkg, oracle, b)
     assert o[3].tolist() == [1, 3, 0, 0, 0, 5]
     assert_same(g, o, b["stream_cfgs"], None)
 
@@ -145,9 +136,8 @@ def _random_recipe_batch(synth, seed, count, stereo, is24):
     return d
 
 
-@pytest.mark.parametrize("variant", [1, 3, 4, 5])
 @pytest.mark.parametrize("stereo,is24,loud", [(True, False, False), (True, True, True), (False, False, True), (False, True, False)])
-def test_random_recipes_vs_oracle(pkg, oracle, synth, variant, stereo, is24, loud):
+def test_random_recipes_vs_oracle(pkg, oracle, synth, stereo, is24, loud):
     d = _random_recipe_batch(synth, 1234 + 2 * stereo + is24, 96, stereo, is24)
     sig = synth.default_signal(77)
     sig["silence_prob"] = 0.3
@@ -155,7 +145,7 @@ def test_random_recipes_vs_oracle(pkg, oracle, synth, variant, stereo, is24, lou
         sig["amp_lo_log2"], sig["amp_hi_log2"], sig["noise_sigma"] = 14.5, 15.0, 9000.0
     b = synth.make_batch(d, sig, want_pcm=True)
     b.update(stream_cfgs=[(4096, 24 if is24 else 16, 40, 10, 14, 2 if stereo else 1)], cfg_idx=None)
-    g, o = run_both(pkg, oracle, b, variant=variant)
+    g, o = run_both(pkg, oracle, b)
     assert (o[3] == 0).all()
     assert_same(g, o, b["stream_cfgs"], None)
     for p in range(len(d)):
@@ -163,8 +153,7 @@ def test_random_recipes_vs_oracle(pkg, oracle, synth, variant, stereo, is24, lou
         assert np.array_equal(g[0][p, :cnt], b["pcm"][p, :cnt])
 
 
-@pytest.mark.parametrize("variant", [1, 3, 5])
-def test_exotic_stream_configs(pkg, oracle, synth, variant):
+def test_exotic_stream_configs(pkg, oracle, synth):
     # other rice parameters than the usual 40/10/14, several stream configs in one batch
     cfgs = [(4096, 16, 40, 10, 14, 2), (4096, 16, 255, 255, 16, 2), (4096, 16, 8, 0, 1, 2), (4096, 24, 100, 3, 9, 2)]
     d = synth.packet_descs(64, n=700, max_samples_per_frame=4096)
@@ -176,13 +165,12 @@ def test_exotic_stream_configs(pkg, oracle, synth, variant):
     d["pred_order"] = np.random.default_rng(5).integers(0, 32, (64, 2))
     b = synth.make_batch(d, synth.default_signal(5), want_pcm=True)
     b.update(stream_cfgs=cfgs, cfg_idx=ci)
-    g, o = run_both(pkg, oracle, b, variant=variant)
+    g, o = run_both(pkg, oracle, b)
     assert (o[3] == 0).all()
     assert_same(g, o, cfgs, ci)
 
 
-@pytest.mark.parametrize("variant", [1, 3, 5])
-def test_mutated_packets_never_hang_and_match(pkg, oracle, synth, variant):
+def test_mutated_packets_never_hang_and_match(pkg, oracle, synth):
     # flip bits in valid packets; every packet is followed by zero padding so that both decoders see
     # zeros past a (possibly now too short) packet.  The kernel must terminate and agree with the oracle
     # on status; where both say OK the PCM must agree too.
@@ -205,7 +193,7 @@ def test_mutated_packets_never_hang_and_match(pkg, oracle, synth, variant):
     b["blob"] = np.frombuffer(bytes(blob), dtype=np.uint8)
     b["offsets"] = np.array(offs, dtype=np.uint64)
     b["sizes"] = np.array(sizes, dtype=np.uint32)
-    g, o = run_both(pkg, oracle, b, variant=variant)
+    g, o = run_both(pkg, oracle, b)
     assert set(np.unique(o[3])) - {0}, "the mutation should break at least some packets"
     assert_same(g, o, b["stream_cfgs"], b["cfg_idx"])
 
@@ -233,14 +221,13 @@ def test_auto_kernel_choice_above_the_big_batch_threshold(pkg, oracle, synth, st
     b = synth.make_batch(d, synth.default_signal(11), want_pcm=True)
     cfgs = [(4096, 16, 40, 10, 14, 2 if stereo else 1)]
     o = oracle.decode_batch(oracle.make_cfgs(cfgs), b["blob"], b["offsets"], b["sizes"], None, b["slot_ints"], n_threads=8)
-    with pkg.AlacGpuContext(cfgs) as ctx:      # variant 0 = auto
+    with pkg.AlacGpuContext(cfgs) as ctx:
         g = ctx.decode_batch(b["blob"], b["offsets"], b["sizes"], None, b["slot_ints"])
     assert (o[3] == 0).all()
     assert_same(g, o, cfgs, None)
 
 
-@pytest.mark.parametrize("variant", [1, 3, 4, 5])
-def test_maximum_frame_length(pkg, oracle, synth, variant):
+def test_maximum_frame_length(pkg, oracle, synth):
     # 16384 samples per channel is the reference's scratch size (AlacFile.cs:28): the longest frame it can decode.
     # 24-bit, shift bytes, order 16 and a hassize header: the ring and the bit cursor wrap many times
     d = synth.packet_descs(6, n=16384, max_samples_per_frame=16384, sample_size=24, stereo=1)
@@ -252,7 +239,7 @@ def test_maximum_frame_length(pkg, oracle, synth, variant):
     sig["silence_prob"] = 0.5
     b = synth.make_batch(d, sig, want_pcm=True)
     b.update(stream_cfgs=[(16384, 24, 40, 10, 14, 2)], cfg_idx=None)
-    g, o = run_both(pkg, oracle, b, variant=variant)
+    g, o = run_both(pkg, oracle, b)
     assert (o[3] == 0).all()
     assert_same(g, o, b["stream_cfgs"], None)
     for p in range(6):
@@ -308,15 +295,13 @@ def test_cpp_host_mirror(pkg, oracle, synth, tmp_path):
     assert out.returncode == 1 and "FIXME: unimplemented sample size 20" in out.stdout
 
 
-@pytest.mark.parametrize("variant", [1, 3, 4, 5])
 @pytest.mark.parametrize("cfg", [2, 3, 4, 5])
-def test_packed_output_equals_format_samples(pkg, oracle, synth, cfg, variant):
+def test_packed_output_equals_format_samples(pkg, oracle, synth, cfg):
     # ALACGPU_OUT_PACKED_LE: the kernel stores what AlacContext.Read returns (FormatSamples fused, AlacContext.cs:214-256)
     b = synth.make_config_batch(cfg, n_packets=48)
     cfgs = oracle.make_cfgs(b["stream_cfgs"])
     opcm, oob, oos, ost = oracle.decode_batch(cfgs, b["blob"], b["offsets"], b["sizes"], b["cfg_idx"], b["slot_ints"], n_threads=8)
     with pkg.AlacGpuContext(b["stream_cfgs"]) as ctx:
-        ctx.set_kernel_variant(variant)
         ctx.set_output_format(1)
         pcm, ob, os_, st = ctx.decode_batch(b["blob"], b["offsets"], b["sizes"], b["cfg_idx"], b["slot_ints"])
     assert np.array_equal(st, ost) and np.array_equal(ob, oob)
@@ -367,9 +352,8 @@ def test_both_two_pass_kernels_share_a_batch(pkg, oracle, synth, out_format):
             assert np.array_equal(raw[p, : len(exp)], exp), f"packet {p}"
 
 
-@pytest.mark.parametrize("variant", [3, 5])
 @pytest.mark.parametrize("stereo", [True, False])
-def test_packed_24bit_low_order_streams(pkg, oracle, synth, variant, stereo):
+def test_packed_24bit_low_order_streams(pkg, oracle, synth, stereo):
     # 24-bit, LPC orders 1..8 (the layout the two-pass kernel takes), shift bytes 0/1/2, packed output: the two-pass
     # kernel parks channel A in the upper half of the slot while the packed bytes grow from its start
     count = 40
@@ -390,7 +374,6 @@ def test_packed_24bit_low_order_streams(pkg, oracle, synth, variant, stereo):
     opcm, oob, oos, ost = oracle.decode_batch(cfgs, b["blob"], b["offsets"], b["sizes"], None, b["slot_ints"], n_threads=8)
     assert (ost == 0).all()
     with pkg.AlacGpuContext(scfg) as ctx:
-        ctx.set_kernel_variant(variant)
         ctx.set_output_format(1)
         pcm, ob, os_, st = ctx.decode_batch(b["blob"], b["offsets"], b["sizes"], None, b["slot_ints"])
     assert np.array_equal(st, ost) and np.array_equal(ob, oob) and np.array_equal(os_, oos)
@@ -428,9 +411,8 @@ def test_host_path_reuses_the_callers_array_and_trims_the_packed_copy(pkg, oracl
         assert (raw[:, bps * slot:] == 0x5A).all()      # beyond what any packet of these cfgs can fill: untouched
 
 
-@pytest.mark.parametrize("variant", [3, 4, 5])
 @pytest.mark.parametrize("stereo,is24", [(True, False), (True, True), (False, False)])
-def test_p8_layout_random(pkg, oracle, synth, variant, stereo, is24):
+def test_p8_layout_random(pkg, oracle, synth, stereo, is24):
     # every stream has 1 <= N <= 8, so the split kernels use the 8-lanes-per-stream reconstruction layout;
     # ragged sample counts, escapes, silence and loud content exercise its generic (masked) steps too
     rng = np.random.default_rng(808 + stereo + 2 * is24)
@@ -443,20 +425,19 @@ def test_p8_layout_random(pkg, oracle, synth, variant, stereo, is24):
     sig["amp_lo_log2"], sig["amp_hi_log2"], sig["noise_sigma"] = 13.0, 15.0, 3000.0
     b = synth.make_batch(d, sig, want_pcm=True)
     b.update(stream_cfgs=[(4096, 24 if is24 else 16, 40, 10, 14, 2 if stereo else 1)], cfg_idx=None)
-    g, o = run_both(pkg, oracle, b, variant=variant)
+    g, o = run_both(pkg, oracle, b)
     assert (o[3] == 0).all()
     assert_same(g, o, b["stream_cfgs"], None)
 
 
-@pytest.mark.parametrize("variant", VARIANTS)
-def test_tiny_batches_and_degenerate_packets(pkg, oracle, synth, variant):
+def test_tiny_batches_and_degenerate_packets(pkg, oracle, synth):
     # partially filled workgroups (1, 2, 3, 5 packets) and packets of 0 / 1 / 2 / 5 bytes (everything past the end
     # reads as zeros for both decoders: each packet is followed by zero padding)
     src = synth.make_config_batch(2, n_packets=5, want_pcm=True)
     for npk in (1, 2, 3, 5):
         b = dict(src)
         b["offsets"], b["sizes"] = src["offsets"][:npk], src["sizes"][:npk]
-        g, o = run_both(pkg, oracle, b, variant=variant)
+        g, o = run_both(pkg, oracle, b)
         assert (o[3] == 0).all()
         assert_same(g, o, b["stream_cfgs"], None)
         assert np.array_equal(g[0], src["pcm"][:npk])
@@ -471,15 +452,14 @@ def test_tiny_batches_and_degenerate_packets(pkg, oracle, synth, variant):
     b["blob"] = np.frombuffer(bytes(blob), dtype=np.uint8)
     b["offsets"] = np.array(offs, dtype=np.uint64)
     b["sizes"] = np.array(sizes, dtype=np.uint32)
-    g, o = run_both(pkg, oracle, b, variant=variant)
+    g, o = run_both(pkg, oracle, b)
     assert o[3].tolist()[-1] == 0 and all(s != 0 for s in o[3].tolist()[:-1])
     assert_same(g, o, b["stream_cfgs"], None)
 
 
-@pytest.mark.parametrize("variant", [3, 4, 5])
 @pytest.mark.parametrize("is24", [False, True])
 @pytest.mark.parametrize("content", ["loud", "one_silent_stream_in_eight", "very_quiet"])
-def test_speculative_tiers_on_full_length_streams(pkg, oracle, synth, variant, is24, content):
+def test_speculative_tiers_on_full_length_streams(pkg, oracle, synth, is24, content):
     # Full-length packets of equal length keep the entropy wave on its speculative units from the first chunk to the
     # last, so the tier a unit lands on is decided by the content alone:
     #   loud                         escape codes in most units (rice_spec_step_esc; _esc_wide for 24-bit raw values)
@@ -514,16 +494,15 @@ def test_speculative_tiers_on_full_length_streams(pkg, oracle, synth, variant, i
         b = dict(blob=blob, offsets=offsets, sizes=sizes, slot_ints=parts[0]["slot_ints"],
                  pcm=np.concatenate([x["pcm"] for x in parts]))
     b.update(stream_cfgs=[(4096, 24 if is24 else 16, 40, 10, 14, 2)], cfg_idx=None)
-    g, o = run_both(pkg, oracle, b, variant=variant)
+    g, o = run_both(pkg, oracle, b)
     assert (o[3] == 0).all()
     assert_same(g, o, b["stream_cfgs"], None)
     assert np.array_equal(g[0][:, :8192], b["pcm"][:, :8192])
 
 
-@pytest.mark.parametrize("variant", [4, 5])
 @pytest.mark.parametrize("stereo", [True, False])
 @pytest.mark.parametrize("orders", [(1, 9), (9, 17), (17, 32)])
-def test_ragged_batches_long_and_short_packets_share_a_workgroup(pkg, oracle, synth, variant, stereo, orders):
+def test_ragged_batches_long_and_short_packets_share_a_workgroup(pkg, oracle, synth, stereo, orders):
     # Most packets are full frames, a few end early at assorted places (chunk boundaries, one sample either side of
     # them, one sample long): in the two-pass kernels a stream that ends becomes a shadow of the longest stream of its wave
     # and the speculative units go on -- in all three FIR arrangements (one tap per lane, two taps per lane, the 32-tap
@@ -542,7 +521,7 @@ def test_ragged_batches_long_and_short_packets_share_a_workgroup(pkg, oracle, sy
     sig["silence_prob"] = 0.1
     b = synth.make_batch(d, sig, want_pcm=True)
     b.update(stream_cfgs=[(4096, 16, 40, 10, 14, 2 if stereo else 1)], cfg_idx=None)
-    g, o = run_both(pkg, oracle, b, variant=variant)
+    g, o = run_both(pkg, oracle, b)
     assert (o[3] == 0).all()
     assert_same(g, o, b["stream_cfgs"], None)
     for p in range(count):

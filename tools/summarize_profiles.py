@@ -9,7 +9,7 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r1_final"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r2_final"
 src = "gpurun_out/final"
 os.makedirs("profiles", exist_ok=True)
 
@@ -59,7 +59,10 @@ out = {
     "effective_clock_GHz": gui / 8 / summary["pmc_write"]["avg_kernel_ns"],
 }
 json.dump(out, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1)
+sys.path.insert(0, os.getcwd())
+import bench as _bench
 json.dump({"workload": "cfg2", "kernel": kernel, "hbm_bytes_per_launch": out["traffic"]["hbm_bytes_per_launch"],
+           "kernel_source_sha": _bench.kernel_source_sha(),   # bench.py reports this figure only for these kernel sources
            "source": f"profiles/{tag}_pmc_summary.json"}, open("profiles/traffic_cfg2.json", "w"))
 shutil.copy(f"{src}/bench_default.json", f"profiles/{tag}_bench_cfg2.json")
 shutil.copy(f"{src}/cfg1_m4a.json", f"profiles/{tag}_cfg1_m4a.json")
