@@ -412,7 +412,7 @@ class AlacContext:
             ref = np.concatenate([ref, np.zeros(need_ints - len(ref), dtype=np.int32)])
         data = format_samples(bps, ref, out_bytes)                # FormatSamples (:168)
         n_out = min(len(data), out_bytes)
-        buffer[:n_out] = data[:n_out]
+        buffer[:n_out] = data[:n_out].tobytes() if isinstance(buffer, (bytearray, memoryview)) else data[:n_out]
         return out_bytes
 
     def SetPosition(self, position):
@@ -420,7 +420,6 @@ class AlacContext:
         r = self._demuxRes
         current_position = 0
         current_sample = 0
-        self._ready = []
         for i, (first_chunk, samples_per_chunk, _) in enumerate(r.Stsc):
             last_chunk = r.Stsc[i + 1][0] if i < len(r.Stsc) - 1 else len(r.Stco)
             for chunk in range(first_chunk, last_chunk + 1):
@@ -434,6 +433,9 @@ class AlacContext:
                         break
                     current_position += info[1]
                     if position < current_position:
+                        # (only now: a position at or past the end is a no-op in the reference, and Read goes on with the
+                        # next packet -- which may be sitting, decoded, in the prefetched batch)
+                        self._ready = []
                         self._stream.Seek(pos)
                         self._currentSampleBlock = current_sample
                         self.LastSampleNumber = current_position

@@ -323,7 +323,6 @@ public:
 
     void SetPosition(long long position) {   // :262-295
         int currentPosition = 0, currentSample = 0;
-        ready_.clear();
         for (size_t i = 0; i < demux_.Stsc.size(); i++) {
             const auto& ci = demux_.Stsc[i];
             int lastChunk = i + 1 < demux_.Stsc.size() ? demux_.Stsc[i + 1].FirstChunk : (int)demux_.Stco.size();
@@ -336,6 +335,7 @@ public:
                     if (!SampleInfo(currentSample, size, dur)) break;
                     currentPosition += dur;
                     if (position < currentPosition) {
+                        ready_.clear();   // only now: a position past the end is a no-op (:262-295), Read goes on with the prefetched packets
                         stream_.Seek(pos);
                         currentSampleBlock_ = currentSample;
                         LastSampleNumber = currentPosition;

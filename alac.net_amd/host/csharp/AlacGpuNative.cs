@@ -1,7 +1,7 @@
 // P/Invoke binding of include/alacgpu.h for the C# host (drop into ALACDecoder/).
 // NOT compiled or executed in this repository's pipeline: the build image has no .NET toolchain.
 // It is kept mechanical -- blittable arguments only -- and mirrors the executed ctypes binding in
-// alac.net_amd/__init__.py one to one.
+// alac.net_amd/__init__.py (SYMBOLS table) one to one.
 using System;
 using System.Runtime.InteropServices;
 
@@ -26,19 +26,28 @@ namespace ALACdotNET.Decoder
 
         public const int StOk = 0, StUnsupportedElement = 1, StUnsupportedSampleSize = 2, StUnsupportedPredType = 3,
                          StBadSampleCount = 4, StOverrun = 5, StRefThrows = 6, StUnsupportedParams = 7;
+        public const int OutInt32 = 0, OutPackedLe = 1;
 
         [DllImport(Lib)] public static extern int alacgpu_version();
+        [DllImport(Lib)] public static extern int alacgpu_device_count();
         [DllImport(Lib)] public static extern int alacgpu_create([In] AlacGpuCfg[] cfgs, uint nCfgs, int device, out IntPtr ctx);
         [DllImport(Lib)] public static extern void alacgpu_destroy(IntPtr ctx);
         [DllImport(Lib)] public static extern int alacgpu_cfg_from_codec_data([In] int[] codecData, uint nInts, int samplesize, int numchannels, out AlacGpuCfg cfg);
         [DllImport(Lib)] public static extern int alacgpu_decode_batch(IntPtr ctx, [In] byte[] blob, ulong blobBytes,
             [In] ulong[] offsets, [In] uint[] sizes, [In] ushort[] cfgIdx, uint nPackets,
             [Out] int[] pcmOut, uint slotInts, [Out] int[] outBytes, [Out] int[] outSamples, [Out] int[] status);
+        // the same entry point over raw pointers (pinned / alacgpu_alloc_pinned memory; packed output viewed as bytes)
+        [DllImport(Lib, EntryPoint = "alacgpu_decode_batch")] public static extern int alacgpu_decode_batch_ptr(IntPtr ctx, IntPtr blob, ulong blobBytes,
+            [In] ulong[] offsets, [In] uint[] sizes, [In] ushort[] cfgIdx, uint nPackets,
+            IntPtr pcmOut, uint slotInts, [Out] int[] outBytes, [Out] int[] outSamples, [Out] int[] status);
         [DllImport(Lib)] public static extern int alacgpu_decode_frame(IntPtr ctx, uint cfgIndex, [In] byte[] inbuffer, uint inBytes,
             [Out] int[] outbuffer, uint outCapacityInts, out int outBytes, out int status);
         /// <summary>0: one int per sample (default); 1: packed little-endian PCM, the bytes AlacContext.Read returns
         /// (AlacContext.FormatSamples fused into the store) at the start of every slot; out_bytes[p] of them.</summary>
         [DllImport(Lib)] public static extern int alacgpu_set_output_format(IntPtr ctx, int format);
+        [DllImport(Lib)] public static extern IntPtr alacgpu_alloc_pinned(UIntPtr bytes);
+        [DllImport(Lib)] public static extern void alacgpu_free_pinned(IntPtr p);
+        [DllImport(Lib)] public static extern float alacgpu_last_kernel_ms(IntPtr ctx);
         [DllImport(Lib)] public static extern IntPtr alacgpu_status_string(int status);
         [DllImport(Lib)] public static extern IntPtr alacgpu_strerror(int rc);
         [DllImport(Lib)] public static extern IntPtr alacgpu_last_error(IntPtr ctx);

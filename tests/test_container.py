@@ -138,3 +138,110 @@ def test_cpp_alaccontext_mirror(synth, tmp_path, sample_size):
     p2.write_bytes(bad)
     out = subprocess.run([exe, str(p2)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 1 and "Error while loading the QuickTime movie headers." in out.stdout
+
+
+@pytest.mark.gpu
+def test_seek_past_the_end_is_a_no_op_and_read_goes_on(synth):
+    # AlacContext.cs:262-295: a position at or past the end changes nothing; the next Read returns the next packet.
+    # With batch prefetch that packet sits decoded in the queue and the stream is ahead: nothing may be dropped.
+    from alac.net_amd import container
+
+    data, packets, pcm, d = make_file(synth, n_packets=9, last=4096)
+    with container.AlacContext(io.BytesIO(data), batch_packets=4) as ctx:
+        buf = np.zeros(1024 * 80, dtype=np.uint8)
+        out = bytearray()
+        n = ctx.Read(buf)
+        out += bytes(buf[:n])
+        last = ctx.LastSampleNumber
+        ctx.SetPosition(9 * 4096)          # == total samples: not found
+        ctx.SetPosition(10**9)
+        assert ctx.LastSampleNumber == last
+        while True:
+            n = ctx.Read(buf)
+            if n <= 0:
+                break
+            out += bytes(buf[:n])
+    assert bytes(out) == pcm.astype("<i2").tobytes()
+
+
+@pytest.mark.gpu
+def test_alaccontext_seek_24bit_quirk(synth):
+    # after a seek into a frame, _offset counts samples x channels but indexes a buffer that holds one
+    # int per BYTE for 24-bit streams, and the byte count drops by _offset x 3 (AlacContext.cs:200-202, :284-286): the
+    # bytes handed out start _offset BYTES into the frame and stop 2 x _offset bytes short of its end.  Reproduced.
+    from alac.net_amd import container
+
+    data, packets, pcm, d = make_file(synth, n_packets=6, sample_size=24, last=4096)
+    packed = b"".join(int(v).to_bytes(4, "little", signed=True)[:3] for v in pcm)
+    fb = 4096 * 2 * 3                       # bytes per frame
+    with container.AlacContext(io.BytesIO(data), batch_packets=3) as ctx:
+        buf = np.zeros(1024 * 80, dtype=np.uint8)
+        for pos in (4096 * 3 + 100, 4096 * 1 + 4000, 7):
+            ctx.SetPosition(pos)
+            n = ctx.Read(buf)
+            frame, k = pos // 4096, pos % 4096
+            off = k * 2                     # _offset (ints == bytes here)
+            assert n == fb - off * 3
+            assert bytes(buf[:n]) == packed[frame * fb + off: frame * fb + off + n]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sample_size", [16, 24])
+def test_alacfilereader_mirror_reads_like_a_wavestream(synth, sample_size):
+    # AlacNetNAudioAdapter/ALACFileReader.cs: WaveFormat, Length, Read(buffer, offset, count) in odd-sized pieces that
+    # straddle packets (the leftover buffer), Position get/set
+    from alac.net_amd.naudio_adapter import ALACFileReader
+
+    data, packets, pcm, d = make_file(synth, n_packets=11, sample_size=sample_size, last=777)
+    bps = sample_size // 8
+    exp = b"".join(int(v).to_bytes(4, "little", signed=True)[:bps] for v in pcm)
+    with ALACFileReader(io.BytesIO(data), batch_packets=4) as r:
+        wf = r.WaveFormat
+        assert (wf.SampleRate, wf.BitsPerSample, wf.Channels, wf.BlockAlign) == (44100, sample_size, 2, 2 * bps)
+        assert r.Length == len(exp) and r.Position == 0
+        out = bytearray()
+        buf = bytearray(20000)
+        sizes = [1, 5000, 16384, 3, 17001, 19990]
+        k = 0
+        while True:
+            want = sizes[k % len(sizes)]
+            k += 1
+            n = r.Read(buf, 7, want)
+            if n == 0:
+                break
+            out += buf[7:7 + n]
+            assert n == want or len(out) == len(exp)
+        assert bytes(out) == exp
+        assert r.Position == r.Length           # LastSampleNumber * BlockAlign at the end of the stream
+    if sample_size == 16:
+        with ALACFileReader(io.BytesIO(data), batch_packets=4) as r:
+            buf = bytearray(70000)
+            r.Read(buf, 0, 1000)                # leaves leftovers in the adapter's buffer
+            pos_bytes = (4096 * 4 + 10) * 4
+            r.Position = pos_bytes              # Program.cs:49 does this from another thread; drops the leftovers
+            n = r.Read(buf, 0, 50000)
+            assert bytes(buf[:n]) == exp[pos_bytes:pos_bytes + 50000]
+
+
+@pytest.mark.gpu
+def test_cpp_alacfilereader_mirror(synth, tmp_path):
+    import os
+    import subprocess
+    import alac.net_amd as pkg
+
+    exe = os.path.join(os.path.dirname(pkg.__file__), "host", "alaccontext_selftest")
+    data, packets, pcm, d = make_file(synth, n_packets=9, sample_size=16, last=555)
+    path = tmp_path / "t.m4a"
+    path.write_bytes(data)
+    exp = pcm.astype("<i2").tobytes()
+    total = int(d["n"].sum())
+    out = subprocess.run([exe, str(path), "reader", "10007"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.strip() == (f"reader rate=44100 bits=16 channels=2 align=4 length={len(exp)} bytes={len(exp)} "
+                                  f"fnv={_fnv(exp)} position={total * 4}"), out.stdout
+    pos = (4096 * 3 + 99) * 4
+    out = subprocess.run([exe, str(path), "reader", "9001", str(pos)], capture_output=True, text=True, timeout=120)
+    rest = exp[pos:]
+    # Position after a seek + reading to the end: the reference's double count of the seek frame (AlacContext.cs:199,:283)
+    assert out.stdout.strip() == (f"reader rate=44100 bits=16 channels=2 align=4 length={len(exp)} bytes={len(rest)} "
+                                  f"fnv={_fnv(rest)} position={(total + 4096) * 4}"), out.stdout
