@@ -372,6 +372,10 @@ class AlacContext:
             slot = 16384 * int(self._cfg[0]["num_channels"])
             pcm, ob, os_, st = self._gpu.decode_batch(blob, offsets, sizes, None, slot)
         self._currentSampleBlock += len(sizes)
+        # a one-channel element with an unknown prediction type: the reference decodes nothing and hands out its stale
+        # buffer without throwing (AlacFile.cs:484-496); here: silence of the same length (status 1 = nothing decoded)
+        first = blob[np.minimum(offsets, max(len(blob) - 1, 0)).astype(np.int64)] if len(blob) else np.zeros(len(sizes), np.uint8)
+        st = np.where((st == 3) & ((first >> 5) == 0) & (sizes > 0), 1, st).astype(np.int32)
         return pcm, ob, os_, st, np.array(durs)
 
     def _raise_for(self, st):

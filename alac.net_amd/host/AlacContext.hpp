@@ -282,6 +282,8 @@ public:
         int rc = alacgpu_decode_batch(ctx_, blob.data(), total, offsets.data(), sizes.data(), nullptr, (uint32_t)n, pcm.data(),
                                       slotInts, outBytes.data(), outSamples.data(), status.data());
         if (rc != ALACGPU_OK) throw std::runtime_error(std::string("alacgpu_decode_batch: ") + alacgpu_strerror(rc));
+        firstByte_.assign(n, 0);
+        for (size_t i = 0; i < n; i++) firstByte_[i] = sizes[i] ? blob[(size_t)offsets[i]] : 0;
         currentSampleBlock_ += (int)n;
         return (int)n;
     }
@@ -297,6 +299,9 @@ public:
             for (int p = 0; p < n; p++) {
                 Packet pk;
                 pk.outBytes = ob[(size_t)p]; pk.samples = os[(size_t)p]; pk.status = st[(size_t)p]; pk.duration = durs[(size_t)p];
+                // a one-channel element with an unknown prediction type: the reference decodes nothing and hands out its
+                // stale buffer without throwing (AlacFile.cs:484-496); here: silence of the same length
+                if (pk.status == ALACGPU_ST_UNSUPPORTED_PREDTYPE && firstByte_[(size_t)p] >> 5 == 0) pk.status = ALACGPU_ST_UNSUPPORTED_ELEMENT;
                 size_t cnt = pk.status == ALACGPU_ST_OK ? (size_t)pk.samples * cfg_.num_channels : 0;
                 pk.pcm.assign(pcm.begin() + (size_t)p * slot, pcm.begin() + (size_t)p * slot + cnt);
                 ready_.push_back(std::move(pk));
@@ -381,6 +386,7 @@ private:
     int batchPackets_;
     int currentSampleBlock_ = 0, offset_ = 0;
     std::deque<Packet> ready_;
+    std::vector<uint8_t> firstByte_;   // of every packet of the last batch (the element's channels field, AlacFile.cs:435)
 };
 
 }}  // namespace ALACdotNET::Decoder

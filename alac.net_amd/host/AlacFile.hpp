@@ -41,6 +41,9 @@ public:
         int32_t out_bytes = 0, status = 0;
         int rc = alacgpu_decode_frame(ctx_, 0, inbuffer, in_bytes, outbuffer, out_capacity, &out_bytes, &status);
         if (rc != ALACGPU_OK) throw std::runtime_error(std::string("alacgpu_decode_frame: ") + alacgpu_strerror(rc));
+        // a one-channel element with an unknown prediction type: the reference skips the predictor silently and hands out
+        // whatever its buffer held (AlacFile.cs:484-496); here the caller's buffer is left as it was
+        if (status == ALACGPU_ST_UNSUPPORTED_PREDTYPE && in_bytes > 0 && (inbuffer[0] >> 5) == 0) return out_bytes;
         throw_for(status);
         return out_bytes;  // AlacFile.cs:718
     }

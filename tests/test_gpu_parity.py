@@ -528,3 +528,41 @@ def test_ragged_batches_long_and_short_packets_share_a_workgroup(pkg, oracle, sy
         cnt = int(n[p]) * (2 if stereo else 1)
         assert np.array_equal(g[0][p, :cnt], b["pcm"][p, :cnt])
 
+
+
+def test_hand_kats_round2_on_gpu(pkg):
+    # the hand-derived vectors of tests/test_oracle_kat.py (round 2: unsigned mix weight, uncompressed 24-bit, history
+    # saturation, run-symbol mask + clz(0) == 40), straight on the GPU, with the expectations written out again
+    from test_oracle_kat import kat_escape24_packet, kat_q19_packet, kat_q20_q1_packet, kat_q3_packet
+
+    cfgs = [(4096, 16, 40, 10, 14, 2), (4096, 24, 40, 10, 14, 2), (4096, 24, 40, 10, 14, 1), (4096, 16, 40, 0, 2, 1)]
+    pk = [kat_q3_packet(), kat_escape24_packet(), kat_q19_packet(), kat_q20_q1_packet()]
+    blob = np.frombuffer(b"".join(pk), dtype=np.uint8)
+    sizes = np.array([len(x) for x in pk], dtype=np.uint32)
+    offsets = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.uint64)
+    with pkg.AlacGpuContext(cfgs) as ctx:
+        pcm, ob, os_, st = ctx.decode_batch(blob, offsets, sizes, np.arange(4, dtype=np.uint16), 64)
+    assert st.tolist() == [0, 0, 0, 0]
+    assert pcm[0, :2].tolist() == [103, 93] and ob[0] == 4
+    assert pcm[1, :2].tolist() == [0x123456, -2] and ob[1] == 6
+    assert pcm[2, :2].tolist() == [35000, -3] and ob[2] == 6
+    assert pcm[3, :5].tolist() == [0, 0, 0, 0, -1] and ob[3] == 10 and os_[3] == 5
+
+
+def test_mono_element_with_unknown_prediction_type_does_not_throw(pkg, synth):
+    # AlacFile.cs:484-496: a one-channel element whose predictionType is not 0 skips the predictor silently (the output is
+    # stale scratch); a two-channel element throws (:650,:660).  The host mirrors reproduce the difference.
+    d = synth.packet_descs(2, n=64, max_samples_per_frame=4096, stereo=0)
+    d["pred_type"][0] = [2, 0]
+    d["stereo"][1] = 1
+    d["pred_type"][1] = [0, 1]
+    b = synth.make_batch(d, synth.default_signal(1))
+    pk = [bytes(b["blob"][int(o):int(o) + int(s)]) for o, s in zip(b["offsets"], b["sizes"])]
+    cd = [0] * 24 + [0, 0, 0x10, 0x00, 0, 16, 40, 10, 14, 2, 0, 255, 0, 0, 0x20, 0xE7, 0, 6, 0x9F, 0xE4, 0, 0, 0xAC, 0x44]
+    f = pkg.AlacFile(16, 2)
+    f.SetInfo(cd)
+    out = np.full(1024 * 80, 7, dtype=np.int32)
+    assert f.DecodeFrame(pk[0], out) == 64 * 4 and (out == 7).all()      # returns outputsize, buffer untouched
+    with pytest.raises(Exception, match="unhandled predicition type"):
+        f.DecodeFrame(pk[1], out)
+    f.Dispose()

@@ -124,3 +124,80 @@ def test_kat11_rice_escape_and_multi_bit(oracle):
     st, res, end = oracle.rice_decode(pack(["10", "101", "0", "00", "10", "010"]), 3, 16, 3000, 14, 40)
     assert st == 0 and res.tolist() == [-6, 0, 4]
     assert end == 5 + 3 + 5
+
+
+# ---- round 2: more hand-derived vectors for the quirks a shared misreading could hide ----------
+# The same packets run on the GPU in tests/test_gpu_parity.py::test_hand_kats_round2_on_gpu.
+def kat_q3_packet():
+    # Q3: interlacingLeftweight is read UNSIGNED (:600).  Stereo 16-bit, n = 1, order 0 both channels, shift 8, weight 200.
+    # rss = 17, history 10 -> k = 1 for the only symbol of each channel; dv(A) = 2 * 100 = 200 and dv(B) = 2 * 10 = 20 are
+    # both > 8 -> escape codes: nine 1s + 17 raw bits.  right = 100 - ((10 * 200) >> 8) = 100 - 7 = 93, left = 93 + 10 = 103.
+    # (A signed reading, 200 -> -56, would give right = 100 - ((-560) >> 8) = 100 + 3 = 103.)
+    return pack([(3, 1), (4, 0), (12, 0), (1, 1), (2, 0), (1, 0), (32, 1), (8, 8), (8, 200),
+                 (4, 0), (4, 0), (3, 4), (5, 0), (4, 0), (4, 0), (3, 4), (5, 0),
+                 (9, 0x1FF), (17, 200), (9, 0x1FF), (17, 20)])
+
+
+def kat_escape24_packet():
+    # uncompressed 24-bit stereo (:678-693): Readbits(16) << 8 | Readbits(8), then sign-extended from 24 bits
+    return pack([(3, 1), (4, 0), (12, 0), (1, 1), (2, 0), (1, 1), (32, 1), (16, 0x1234), (8, 0x56), (16, 0xFFFF), (8, 0xFE)])
+
+
+def kat_q19_packet():
+    # Q19: history becomes 0xFFFF when the decoded value exceeds 0xFFFF (:229) -- not a clamp of the running sum.
+    # Mono 24-bit, n = 2, order 0, rss = 24.  Symbol 1: history 10 -> k = 1; escape, raw 70000 -> residual +35000; history :=
+    # 0xFFFF.  Symbol 2: (0xFFFF >> 9) + 3 = 130, clz = 24, initialK = 31 - 14 - 24 = -7 -> k = 7: '0' + '0000110' (e = 6) ->
+    # dv = 0 * 127 + 5 = 5 -> residual -(6 / 2) = -3.  (With history = 10 + 70000 * 40 the second k would be 14.)
+    return pack([(3, 0), (4, 0), (12, 0), (1, 1), (2, 0), (1, 0), (32, 2), (8, 0), (8, 0), (4, 0), (4, 0), (3, 4), (5, 0),
+                 (9, 0x1FF), (24, 70000), "0", "0000110"])
+
+
+def kat_q20_q1_packet():
+    # Q20 + Q1: the zero-run symbol is masked with (1 << kmod) - 1 (:236), the value symbol is not (:224); and
+    # CountLeadingZeros(0) == 40 makes the run symbol's k = 40 + 0 - 24 = 16 when history is 0 (:234).
+    # Stream cfg: initial history 0, k modifier 2; packet: mono 16-bit, n = 5, order 0, rice modifier 0 (history never moves).
+    # value: k = 1, '0' -> 0.  run: k = 16, '10' + 16 zero bits: x = 1, e = 0 -> block = 1 * (65535 & 3) = 3, one bit un-read.
+    # that bit ('0') is the next value symbol: 0 + signModifier 1 -> dv = 1 -> -1.  4 + 1 < 5 is false: no further run.
+    return pack([(3, 0), (4, 0), (12, 0), (1, 1), (2, 0), (1, 0), (32, 5), (8, 0), (8, 0), (4, 0), (4, 0), (3, 0), (5, 0),
+                 "0", "10", "0" * 16])
+
+
+def test_kat12_unsigned_mix_weight(oracle):
+    st, pcm, out_bytes, n = oracle.decode_frame(CFG16_ST, kat_q3_packet())
+    assert st == 0 and n == 1 and out_bytes == 4 and pcm.tolist() == [103, 93]
+
+
+def test_kat13_uncompressed_24bit(oracle):
+    st, pcm, out_bytes, n = oracle.decode_frame((4096, 24, 40, 10, 14, 2), kat_escape24_packet())
+    assert st == 0 and n == 1 and out_bytes == 6 and pcm.tolist() == [0x123456, -2]
+
+
+def test_kat14_history_saturation(oracle):
+    st, pcm, out_bytes, n = oracle.decode_frame((4096, 24, 40, 10, 14, 1), kat_q19_packet())
+    assert st == 0 and n == 2 and out_bytes == 6 and pcm.tolist() == [35000, -3]
+    st, res, end = oracle.rice_decode(pack([(9, 0x1FF), (24, 70000), "0", "0000110"]), 2, 24, 10, 14, 40)
+    assert st == 0 and res.tolist() == [35000, -3] and end == 9 + 24 + 8
+
+
+def test_kat15_run_symbol_mask_and_clz_of_zero(oracle):
+    st, pcm, out_bytes, n = oracle.decode_frame((4096, 16, 40, 0, 2, 1), kat_q20_q1_packet())
+    assert st == 0 and n == 5 and out_bytes == 10 and pcm.tolist() == [0, 0, 0, 0, -1]
+    st, res, end = oracle.rice_decode(pack(["0", "10", "0" * 16]), 5, 16, 0, 2, 0)
+    assert st == 0 and res.tolist() == [0, 0, 0, 0, -1] and end == 19
+
+
+def test_kat16_order20_fir_both_signs(oracle):
+    # order 20, q = 2, coefficient table all zero except coef[19] = 4: warm-up (:284-293) gives out[i] = i + 1 for residuals
+    # of 1 (i = 0..20); then i = 21 (base index 0): sum = (out[1] - out[0]) * coef[19] = 1 * 4 -> (2 + 4) >> 2 = 1;
+    # out[21] = 1 + out[0] + err.  err = +3: out[21] = 1 + 1 + 3 = 5; adaptation (err > 0), oldest tap first (p = 19):
+    # d = out[0] - out[1] = -1, sign -1 -> coef[19] = 5, e -= ((-1 * -1) >> 2) * 1 = 0 -> e stays 3; p = 18: d = out[0] -
+    # out[2] = -2 -> coef[18] = 1, e -= (2 >> 2) * 2 = 0; ... p = 16: d = -4 -> coef[16] = 1, e -= (4 >> 2) * 4 = 4 -> e = -1: stop.
+    # i = 22 (base index 1): sum = (out[2]-out[1]) * coef[19] + (out[3]-out[1]) * coef[18] + (out[4]-out[1]) * coef[17] +
+    #   (out[5]-out[1]) * coef[16] = 1*5 + 2*1 + 3*1 + 4*1 = 14 -> (2 + 14) >> 2 = 4; err = -2: out[22] = 4 + 2 - 2 = 4;
+    # adaptation (err < 0): p = 19: d = out[1] - out[2] = -1, sign = -sgn(d) = +1 -> coef[19] = 4; d * sign = -1; e -= (-1 >> 2) * 1
+    #   = -(-1) -> e = -1; p = 18: d = -2 -> coef[18] = 0; d * sign = -2 -> (-2 >> 2) = -1, times 2 -> e = -1 + 2 = 1: stop.
+    err = [1] * 21 + [3, -2]
+    coefs = [0] * 19 + [4]
+    out, coef = oracle.predictor(err, 16, coefs, 2)
+    assert out.tolist() == list(range(1, 22)) + [5, 4]
+    assert coef.tolist() == [0] * 16 + [1, 1, 0, 4]
