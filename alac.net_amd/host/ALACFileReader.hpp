@@ -24,11 +24,12 @@ public:
     explicit ALACFileReader(std::istream& baseStream, int device = 0, int batchPackets = 256)
         : alacContext_(baseStream, device, batchPackets),                                                   // :41
           waveFormat_(alacContext_.GetSampleRate(), alacContext_.GetBytesPerSample() * 8, alacContext_.GetNumChannels()),   // :42
-          Length((long long)alacContext_.GetNumSamples() * waveFormat_.BlockAlign),                          // :43
-          decompressBuffer_((size_t)65546 * (size_t)(waveFormat_.BitsPerSample / 8) * (size_t)waveFormat_.Channels) {}   // :44
+          decompressBuffer_((size_t)65546 * (size_t)(waveFormat_.BitsPerSample / 8) * (size_t)waveFormat_.Channels) {   // :44
+        Length = (long long)alacContext_.GetNumSamples() * waveFormat_.BlockAlign;                           // :43
+    }
 
     const WaveFormat& GetWaveFormat() const { return waveFormat_; }
-    const long long Length;
+    long long Length = 0;   // bytes of the uncompressed wave stream
 
     long long GetPosition() { return (long long)alacContext_.LastSampleNumber * waveFormat_.BlockAlign; }   // :65
     void SetPosition(long long value) {                                                                      // :66-73
