@@ -54,6 +54,8 @@ struct alac_decode_params {
 extern "C" __global__ void alac_decode_ab_kernel(alac_decode_params p);
 // the same for everything else (LPC orders 17..31, delta mode, order 0): two FIR waves (16-lane layout, 2 tap registers)
 extern "C" __global__ void alac_decode_ab32_kernel(alac_decode_params p);
+// the main kernel with 16 packets / 320-thread workgroup (one entropy wave for 16 streams): big batches
+extern "C" __global__ void alac_decode_ab_dense_kernel(alac_decode_params p);
 #endif
 
 #endif

@@ -183,7 +183,6 @@ __device__ __forceinline__ int mirror_i(int v, int src) { return __shfl(v, src, 
 // Parking place: ints [n, 2n) of the slot (slot_ints >= 2n for two channels).  The final stores of sample i touch
 // at most int 2i+1 (int32 output) or byte 6i+5 (packed), always below the parked samples not yet consumed.
 // ===================================================================================================================
-constexpr int AB_PPW = 8;
 
 // The rings are topped up by the OUTPUT wave (which idles most of the time) instead of the entropy wave (which is the
 // critical one): the entropy wave publishes how far each stream has read, at every chunk barrier; the output wave then
@@ -194,16 +193,21 @@ constexpr int AB_PPW = 8;
 #define ALAC_AB_CHUNK 32
 #endif
 constexpr int AB_CHUNK = ALAC_AB_CHUNK;   // samples per barrier: twice the split kernels' (half the per-chunk overhead of the critical wave)
-struct AbShared {
-    uint32_t rings[8][RING_BYTES / 4];
-    int resq[2][AB_CHUNK][8];
-    int zeros[AB_CHUNK][8];    // residuals of a switched-off stream
-    int outq[2][AB_CHUNK / 8][64];   // FIR wave -> output wave, 8 outputs per stream per 8 samples
-    int dummy[AB_CHUNK * 8 + 64];
-    uint32_t ring_next[8];     // entropy wave -> output wave: Rice::next of the stream at the last barrier
-    uint32_t ring_filled[8];   // entropy wave -> output wave at the start of a pass: bytes staged by rice_init
-    uint32_t ring_on[8];       // stream switched on in this pass
+// NS = streams (packets) per workgroup: 8 (one entropy wave of 8 lanes per stream, one FIR wave, one output wave) or 16 (the
+// "dense" arrangement for big batches: ONE entropy wave serves 16 streams with 4 lanes each -- its instructions, more than half
+// of all the kernel issues, are shared by twice as many packets -- next to two FIR waves and two output waves of 8 streams).
+template <int NS>
+struct AbSharedT {
+    uint32_t rings[NS][RING_BYTES / 4];
+    int resq[2][AB_CHUNK][NS];
+    int zeros[AB_CHUNK][NS];   // residuals of a switched-off stream
+    int outq[2][AB_CHUNK / 8][NS * 8];   // FIR wave w -> output wave w (lanes 64 w ..), 8 outputs per stream per 8 samples
+    int dummy[AB_CHUNK * NS + 64];
+    uint32_t ring_next[NS];    // entropy wave -> output wave: Rice::next of the stream at the last barrier
+    uint32_t ring_filled[NS];  // entropy wave -> output wave at the start of a pass: bytes staged by rice_init
+    uint32_t ring_on[NS];      // stream switched on in this pass
 };
+typedef AbSharedT<8> AbShared;
 
 // One entropy pass over stream `g` of every lane group (S = 8 streams, 8 lanes each): the main pass of entropy_wave.
 // Returns the bit position after the last symbol; *flags collects rice_step's flags.
@@ -211,10 +215,10 @@ struct AbShared {
 // and converts it, fir8_step<.., true>): the inverse of r = (dv >> 1) ^ -(dv & 1) for what rice_step hands back.
 __device__ __forceinline__ int ab_zigzag(int r) { return (int)(((uint32_t)r << 1) ^ (uint32_t)(r >> 31)); }
 
-template <bool RAW>
-__device__ __forceinline__ uint32_t ab_entropy_pass(const alac_decode_params& p, AbShared& sh, const Meta& m, const RiceCfg& rc, int init_hist,
+template <bool RAW, int NS>
+__device__ __forceinline__ uint32_t ab_entropy_pass(const alac_decode_params& p, AbSharedT<NS>& sh, const Meta& m, const RiceCfg& rc, int init_hist,
                                     uint32_t startbit, bool stream_on, int g, int sub, int lane, int nchunks, int* flags_out) {
-    constexpr int S = 8, LPS = 8;
+    constexpr int S = NS, LPS = 64 / NS;
     const int n_row = stream_on ? m.n : 0;
     int flags = 0;
     int full_left = 0;
@@ -341,9 +345,10 @@ __device__ __forceinline__ uint32_t ab_entropy_pass(const alac_decode_params& p,
     return ended ? endpos : rice_bitpos(rs);
 }
 
-template <int P>
-__device__ __forceinline__ void ab_entropy_wave(const alac_decode_params& p, uint32_t pkt0, int lane, AbShared& sh, int nch0, int nch1) {
-    const int g = lane >> 3, sub = lane & 7;
+template <int P, int NS>
+__device__ __forceinline__ void ab_entropy_wave(const alac_decode_params& p, uint32_t pkt0, int lane, AbSharedT<NS>& sh, int nch0, int nch1) {
+    constexpr int LPS = 64 / NS;
+    const int g = lane / LPS, sub = lane % LPS;
     const uint32_t pkt = pkt0 + (uint32_t)g;
     const bool valid = pkt < p.n_packets;
     alacgpu_cfg_dev cfg;
@@ -365,7 +370,7 @@ __device__ __forceinline__ void ab_entropy_wave(const alac_decode_params& p, uin
     for (int ph = 0; ph < (nch1 > 0 ? 2 : 1); ph++) {
         int fl = 0;
         rc.hist_mult = (ph ? mb.ricemod : m.ricemod) * (cfg.rice_history_mult / 4);
-        const uint32_t end = ab_entropy_pass<P == 8>(p, sh, m, rc, cfg.rice_initial_history, ph ? end_a : m.ricebit,
+        const uint32_t end = ab_entropy_pass<P == 8, NS>(p, sh, m, rc, cfg.rice_initial_history, ph ? end_a : m.ricebit,
                                              compressed && (ph == 0 || m.stereo), g, sub, lane, ph ? nch1 : nch0, &fl);
         if (ph == 0) { end_a = end_b = end; flags_a = fl; }
         else { end_b = end; flags_b = fl; }
@@ -396,10 +401,12 @@ __device__ __forceinline__ void ab_entropy_wave(const alac_decode_params& p, uin
 }
 
 // FIR wave: the P8 layout of recon8_wave with the 8 rows' two parities holding the SAME channel of 8 different packets.
-__device__ __forceinline__ void ab_fir_wave(const alac_decode_params& p, uint32_t pkt0, int lane, AbShared& sh, int ph, int nchunks) {
-    constexpr int S = 8;
+// w: which block of 8 streams of the workgroup this wave serves (always 0 when NS == 8).
+template <int NS>
+__device__ __forceinline__ void ab_fir_wave(const alac_decode_params& p, uint32_t pkt0, int w, int lane, AbSharedT<NS>& sh, int ph, int nchunks) {
+    constexpr int S = NS;
     const int row = lane >> 4, l = lane & 15, par = l & 1, j = l >> 1;
-    const int g = 2 * row + par;
+    const int g = 8 * w + 2 * row + par;
     const uint32_t pkt = pkt0 + (uint32_t)g;
     const bool valid = pkt < p.n_packets;
     alacgpu_cfg_dev cfg;
@@ -452,17 +459,18 @@ __device__ __forceinline__ void ab_fir_wave(const alac_decode_params& p, uint32_
                     }
                 }
             }
-            sh.outq[c & 1][half][lane] = f.hist;
+            sh.outq[c & 1][half][64 * w + lane] = f.hist;
         }
     }
     wg_sync();  // final barrier of the pass
 }
 
 // The same wave for workgroups in which some stream has 9 <= N <= 16: two taps per lane (fir8x2_step).
-__device__ __forceinline__ void ab_fir_wave2(const alac_decode_params& p, uint32_t pkt0, int lane, AbShared& sh, int ph, int nchunks) {
-    constexpr int S = 8;
+template <int NS>
+__device__ __forceinline__ void ab_fir_wave2(const alac_decode_params& p, uint32_t pkt0, int w, int lane, AbSharedT<NS>& sh, int ph, int nchunks) {
+    constexpr int S = NS;
     const int row = lane >> 4, l = lane & 15, par = l & 1, j = l >> 1;
-    const int g = 2 * row + par;
+    const int g = 8 * w + 2 * row + par;
     const uint32_t pkt = pkt0 + (uint32_t)g;
     const bool valid = pkt < p.n_packets;
     alacgpu_cfg_dev cfg;
@@ -516,7 +524,7 @@ __device__ __forceinline__ void ab_fir_wave2(const alac_decode_params& p, uint32
                     }
                 }
             }
-            sh.outq[c & 1][half][lane] = f.hist[0];
+            sh.outq[c & 1][half][64 * w + lane] = f.hist[0];
         }
     }
     wg_sync();  // final barrier of the pass
@@ -609,6 +617,7 @@ __device__ __forceinline__ int ab_finish24(const Meta& m, int val, int i, int ch
 }
 
 // Ring refill service of the output wave (see AbShared): lane group r = lane >> 3 serves stream r, 16 bytes per lane.
+template <int NS>
 struct AbRefill {
     static constexpr int ROUNDS = AB_CHUNK / 16;   // up to 8 bytes per sample per stream per chunk (a sample consumes at most 59 bits)
     // a sample costs at most 59 bits (a run-length symbol, 9 + 16, and an escaped value, 9 + 25): never fall behind
@@ -619,13 +628,13 @@ struct AbRefill {
                   "a chunk this long can outrun a ring this small");
     const uint8_t* base;
     int64_t limit;
-    AbShared& sh;
+    AbSharedT<NS>& sh;
     uint32_t* ring;
     int r, sub;
     uint32_t filled = 0, cnt = 0;
     uint4 v[ROUNDS];
-    __device__ AbRefill(const alac_decode_params& p, uint32_t pkt0, int lane, AbShared& sh_) : sh(sh_) {
-        r = lane >> 3;
+    __device__ AbRefill(const alac_decode_params& p, uint32_t pkt0, int w, int lane, AbSharedT<NS>& sh_) : sh(sh_) {
+        r = 8 * w + (lane >> 3);
         sub = lane & 7;
         ring = sh.rings[r];
         const uint32_t pk = pkt0 + (uint32_t)r;
@@ -671,38 +680,54 @@ struct AbRefill {
 
 // Lane -> (stream g, sample j of a block of 8): P == 8 reads the FIR wave's P8 layout lane for lane; P == 16 lets lane
 // group g = lane >> 3 pick its stream's 16 outputs per block of 16 out of the two FIR waves' P16 layouts, 8 and 8.
-template <int P>
-__device__ __forceinline__ int ab_outq_read(const AbShared& sh, int c, int half, int lane, int g, int j) {
-    if (P == 8) return sh.outq[c & 1][half][lane];        // lane (2t + par) holds out[last - t] of its stream
+template <int P, int NS>
+__device__ __forceinline__ int ab_outq_read(const AbSharedT<NS>& sh, int c, int half, int w, int lane, int g, int j) {
+    if (P == 8) return sh.outq[c & 1][half][64 * w + lane];   // lane (2t + par) holds out[last - t] of its stream
     return sh.outq[c & 1][(half & ~1) + (g >> 2)][((g & 3) << 4) + j + 8 * (half & 1)];
 }
 
-template <int P>
-__device__ __forceinline__ void ab_output_wave(const alac_decode_params& p, uint32_t pkt0, int lane, AbShared& sh, int nch0, int nch1) {
-    const int row = lane >> 4, l = lane & 15, par = l & 1;
-    const int j = P == 8 ? l >> 1 : lane & 7;
-    const int g = P == 8 ? 2 * row + par : lane >> 3;
-    const uint32_t pkt = pkt0 + (uint32_t)g;
-    const bool valid = pkt < p.n_packets;
-    alacgpu_cfg_dev cfg;
-    const Meta m = parse_meta(p, pkt, 0, valid, cfg);
-    const int n_out = (valid && m.status == 0) ? m.n : 0;
-    const bool two_pass = n_out > 0 && m.stereo && !m.esc;   // A is parked in pass 0 and finished in pass 1
-    int32_t* pcm_slot = p.pcm_out + (int64_t)pkt * p.slot_ints;
-    int32_t* park = pcm_slot + m.n;
-    AbRefill rf(p, pkt0, lane, sh);
-    // ---- pass 0 ----
-    for (int c = 0; c <= nch0; c++) {
-        wg_sync();  // barrier c: chunk c-1's outputs are in the queue
+// The output work for one block of 8 streams (block w of the workgroup): what happens between two chunk barriers of pass 0
+// (pass0_step) and of pass 1 (pass1_step).  One output wave serves one block (8-packet workgroups) or both blocks of a
+// 16-packet workgroup, one after the other, between the same two barriers.
+template <int P, int NS>
+struct AbOutBlock {
+    const alac_decode_params& p;
+    AbSharedT<NS>& sh;
+    int w, lane, j, g;
+    Meta m;
+    int n_out;
+    bool two_pass;
+    int32_t* pcm_slot;
+    int32_t* park;
+    AbRefill<NS> rf;
+    int a_next[AB_CHUNK / 8];
+    __device__ AbOutBlock(const alac_decode_params& p_, uint32_t pkt0, int w_, int lane_, AbSharedT<NS>& sh_)
+        : p(p_), sh(sh_), w(w_), lane(lane_), rf(p_, pkt0, w_, lane_, sh_) {
+        const int row = lane >> 4, l = lane & 15, par = l & 1;
+        j = P == 8 ? l >> 1 : lane & 7;
+        g = P == 8 ? 8 * w + 2 * row + par : lane >> 3;
+        const uint32_t pkt = pkt0 + (uint32_t)g;
+        const bool valid = pkt < p.n_packets;
+        alacgpu_cfg_dev cfg;
+        m = parse_meta(p, pkt, 0, valid, cfg);
+        n_out = (valid && m.status == 0) ? m.n : 0;
+        two_pass = n_out > 0 && m.stereo && !m.esc;   // A is parked in pass 0 and finished in pass 1
+        pcm_slot = p.pcm_out + (int64_t)pkt * p.slot_ints;
+        park = pcm_slot + m.n;
+#pragma unroll
+        for (int h = 0; h < AB_CHUNK / 8; h++) a_next[h] = 0;
+    }
+    // after barrier c of pass 0: chunk c-1's outputs are in the queue
+    __device__ __forceinline__ void pass0_step(int c, int nch0) {
         if (c < nch0) rf.issue(c == 0);
-        if (c == 0) { rf.commit(); continue; }
+        if (c == 0) { rf.commit(); return; }
 #pragma unroll
         for (int half = 0; half < AB_CHUNK / 8; half++) {
             const int ih = (c - 1) * AB_CHUNK + (P == 8 ? 8 * half : 16 * (half >> 1));   // start of the FIR layout's block
             const int jb = P == 8 ? j : j + 8 * (half & 1);                                   // position in that block
             const int cnt = min(P, n_out - ih);
             if (jb >= cnt) continue;
-            const int mine = ab_outq_read<P>(sh, c - 1, half, lane, g, j);
+            const int mine = ab_outq_read<P, NS>(sh, c - 1, half, w, lane, g, j);
             if (m.esc) {                                            // uncompressed: raw samples, both channels now
                 const int i = ih + jb;
                 const int nch = m.stereo ? 2 : 1;
@@ -725,11 +750,8 @@ __device__ __forceinline__ void ab_output_wave(const alac_decode_params& p, uint
         }
         if (c < nch0) rf.commit();
     }
-    if (nch1 == 0) return;
-    // ---- pass 1: B arrives, A comes back from its parking place (loaded one chunk ahead) ----
-    int a_next[AB_CHUNK / 8] = {};
-    for (int c = 0; c <= nch1; c++) {
-        wg_sync();
+    // after barrier c of pass 1: B arrives, A comes back from its parking place (loaded one chunk ahead)
+    __device__ __forceinline__ void pass1_step(int c, int nch1) {
         if (c < nch1) rf.issue(c == 0);
         int a_cur[AB_CHUNK / 8];
 #pragma unroll
@@ -741,7 +763,7 @@ __device__ __forceinline__ void ab_output_wave(const alac_decode_params& p, uint
             const int cnt = min(P, n_out - ih);
             a_next[half] = (two_pass && c < nch1 && jb < cnt) ? park[ih + cnt - 1 - jb] : 0;
         }
-        if (c == 0) { rf.commit(); continue; }
+        if (c == 0) { rf.commit(); return; }
 #pragma unroll
         for (int half = 0; half < AB_CHUNK / 8; half++) {
             const int ih = (c - 1) * AB_CHUNK + (P == 8 ? 8 * half : 16 * (half >> 1));
@@ -749,7 +771,7 @@ __device__ __forceinline__ void ab_output_wave(const alac_decode_params& p, uint
             const int cnt = min(P, n_out - ih);
             if (!two_pass || jb >= cnt) continue;
             const int i = ih + cnt - 1 - jb;
-            const int a = a_cur[half], b = ab_outq_read<P>(sh, c - 1, half, lane, g, j);
+            const int a = a_cur[half], b = ab_outq_read<P, NS>(sh, c - 1, half, w, lane, g, j);
             int left, right;
             if (m.mixweight != 0) {                                 // AlacFile.cs:346-357 / :377-388
                 right = wsub(a, wmul(b, m.mixweight) >> (m.mixshift & 31));
@@ -763,20 +785,50 @@ __device__ __forceinline__ void ab_output_wave(const alac_decode_params& p, uint
         }
         if (c < nch1) rf.commit();
     }
+};
+
+template <int P, int NS>
+__device__ __forceinline__ void ab_output_wave(const alac_decode_params& p, uint32_t pkt0, int lane, AbSharedT<NS>& sh, int nch0, int nch1) {
+    AbOutBlock<P, NS> b0(p, pkt0, 0, lane, sh);
+    if constexpr (NS == 16) {
+        AbOutBlock<P, NS> b1(p, pkt0, 1, lane, sh);
+        for (int c = 0; c <= nch0; c++) {
+            wg_sync();
+            b0.pass0_step(c, nch0);
+            b1.pass0_step(c, nch0);
+        }
+        if (nch1 == 0) return;
+        for (int c = 0; c <= nch1; c++) {
+            wg_sync();
+            b0.pass1_step(c, nch1);
+            b1.pass1_step(c, nch1);
+        }
+    } else {
+        for (int c = 0; c <= nch0; c++) {
+            wg_sync();
+            b0.pass0_step(c, nch0);
+        }
+        if (nch1 == 0) return;
+        for (int c = 0; c <= nch1; c++) {
+            wg_sync();
+            b0.pass1_step(c, nch1);
+        }
+    }
 }
 
-template <int P>
+template <int P, int NS = 8>
 __device__ __forceinline__ void ab_kernel_body(const alac_decode_params& p) {
-    __shared__ __attribute__((aligned(1024))) AbShared sh;
+    static_assert(NS == 8 || (P == 8 && NS == 16), "the dense arrangement exists for the main kernel only");
+    __shared__ __attribute__((aligned(1024))) AbSharedT<NS> sh;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t pkt0 = blockIdx.x * (uint32_t)AB_PPW;
+    const uint32_t pkt0 = blockIdx.x * (uint32_t)NS;
     // ab_flags[group]: 0 = decoded by alac_decode_ab_kernel, 2 = by alac_decode_ab32_kernel, 1 = left to the split kernel
     if (P == 16 && (!p.ab_flags || p.ab_flags[blockIdx.x] == 0u)) return;
     // every wave reads all 8 headers: pass lengths (uniform over the workgroup) and whether the P8 layout fits
     int n0 = 0, n1 = 0;
     bool bad = false, wide_lane = false;
     {
-        const uint32_t pk = pkt0 + (uint32_t)(lane & 7);
+        const uint32_t pk = pkt0 + (uint32_t)(lane & (NS - 1));
         const bool v = pk < p.n_packets;
         alacgpu_cfg_dev c;
         const Meta ma = parse_meta(p, pk, 0, v, c);
@@ -791,15 +843,21 @@ __device__ __forceinline__ void ab_kernel_body(const alac_decode_params& p) {
         bad = bad || (n1 > 0 && (uint64_t)2 * (uint64_t)ma.n > p.slot_ints);
     }
     const bool fallback = __builtin_amdgcn_ballot_w64(bad) != 0;
-    const bool wide = __builtin_amdgcn_ballot_w64(wide_lane) != 0;   // some stream has more than 8 taps: two taps per lane
+    // some stream (of the block of 8 a FIR wave serves) has more than 8 taps: two taps per lane
+    const bool wide = __builtin_amdgcn_ballot_w64(wide_lane && (lane & (NS - 1)) < 8) != 0;
+    const bool wide1 = NS > 8 && __builtin_amdgcn_ballot_w64(wide_lane && (lane & (NS - 1)) >= 8) != 0;
     if (P == 8) {
-        if (p.ab_flags && threadIdx.x == 0) p.ab_flags[blockIdx.x] = fallback ? 1u : 0u;
+        if (p.ab_flags && threadIdx.x == 0) {   // one flag per 8 packets (the 32-tap kernel works in groups of 8)
+            const uint32_t f0 = blockIdx.x * (uint32_t)(NS / 8);
+            p.ab_flags[f0] = fallback ? 1u : 0u;
+            if (NS > 8 && pkt0 + 8u < p.n_packets) p.ab_flags[f0 + 1] = fallback ? 1u : 0u;
+        }
     } else {
         if (!fallback && threadIdx.x == 0) p.ab_flags[blockIdx.x] = 2u;
         // Nothing is launched behind this kernel in auto mode.  What it cannot take would be a two-channel packet without
         // room for parking in its slot -- which cannot pass the header check (parse_meta: two channels only in a
         // two-channel stream cfg, and then 2 n <= slot_ints).  Should that ever change, fail loudly rather than skip:
-        if (fallback && threadIdx.x < (unsigned)AB_PPW && pkt0 + threadIdx.x < p.n_packets) {
+        if (fallback && threadIdx.x < (unsigned)NS && pkt0 + threadIdx.x < p.n_packets) {
             p.status[pkt0 + threadIdx.x] = ALACGPU_ST_UNSUPPORTED_PARAMS_D;
             if (p.out_bytes) p.out_bytes[pkt0 + threadIdx.x] = 0;
             if (p.out_samples) p.out_samples[pkt0 + threadIdx.x] = 0;
@@ -808,7 +866,7 @@ __device__ __forceinline__ void ab_kernel_body(const alac_decode_params& p) {
     if (fallback) return;
     const int nch0 = (__builtin_amdgcn_readfirstlane(wave_max(n0)) + AB_CHUNK - 1) / AB_CHUNK;
     const int nch1 = (__builtin_amdgcn_readfirstlane(wave_max(n1)) + AB_CHUNK - 1) / AB_CHUNK;
-    for (int t = threadIdx.x; t < AB_CHUNK * 8; t += blockDim.x) (&sh.zeros[0][0])[t] = 0;
+    for (int t = threadIdx.x; t < AB_CHUNK * NS; t += blockDim.x) (&sh.zeros[0][0])[t] = 0;
     if (p.dbg && lane == 0) {   // diagnostic (ALACGPU_DEBUG_STAMPS): where each wave runs, when the workgroup starts
         const unsigned hw = __builtin_amdgcn_s_getreg(63492), xcc = __builtin_amdgcn_s_getreg(63508);
         if (wave == 0) {
@@ -833,7 +891,7 @@ __device__ __forceinline__ void ab_kernel_body(const alac_decode_params& p) {
         const uint32_t my_simd = (hw >> 4) & 3u;
         if (threadIdx.x == 0) {
             const uint32_t cu = ((__builtin_amdgcn_s_getreg(63508) & 7u) << 8) | (((hw >> 13) & 7u) << 5) | (((hw >> 12) & 1u) << 4) | ((hw >> 8) & 15u);
-            sh.ring_next[7] = atomicAdd(&p.cu_arrivals[cu], 1u);                    // (ring_next / ring_on are free until the first pass)
+            sh.ring_next[NS - 1] = atomicAdd(&p.cu_arrivals[cu], 1u);               // (ring_next / ring_on are free until the first pass)
         }
         if (lane == 0) sh.ring_on[wave] = my_simd;
         wg_sync();
@@ -842,26 +900,35 @@ __device__ __forceinline__ void ab_kernel_body(const alac_decode_params& p) {
             // the 32-tap kernel has four working waves, two of them FIR: with up to two workgroups per CU a step of two
             // SIMDs per turn pairs every FIR wave with an entropy or an output wave instead of another FIR wave
             const uint32_t step = (P == 16 && gridDim.x <= 512u) ? 2u : 1u;
-            role = (int)((my_simd - step * sh.ring_next[7]) & 3u);
+            role = (int)((my_simd - step * sh.ring_next[NS - 1]) & 3u);
         }
     }
-    if (P == 8 && role == 3) return;     // the main kernel's fourth wave was only there to claim the fourth SIMD
+    if (P == 8 && NS == 8 && role == 3) return;     // the main kernel's fourth wave was only there to claim the fourth SIMD
     wg_sync();
     if (role == 0) {
         __builtin_amdgcn_s_setprio(ALAC_ENTROPY_PRIO);
-        ab_entropy_wave<P>(p, pkt0, lane, sh, nch0, nch1);
+        ab_entropy_wave<P, NS>(p, pkt0, lane, sh, nch0, nch1);
         if (p.dbg && lane == 0) p.dbg[8 * blockIdx.x + 2] = clock64();
     } else if (role == 1) {
-        ab_output_wave<P>(p, pkt0, lane, sh, nch0, nch1);
-    } else if (P == 16) {
+        ab_output_wave<P, NS>(p, pkt0, lane, sh, nch0, nch1);
+    } else if constexpr (NS == 16) {
+        // dense arrangement: the fourth wave works too -- FIR waves for streams 0..7 (role 2) and 8..15 (role 3)
+        __builtin_amdgcn_s_setprio(1);
+        const int w = role - 2;
+        if (__builtin_expect(!(w ? wide1 : wide), 1)) {
+            for (int ph = 0; ph < (nch1 > 0 ? 2 : 1); ph++) ab_fir_wave<NS>(p, pkt0, w, lane, sh, ph, ph ? nch1 : nch0);
+        } else {
+            for (int ph = 0; ph < (nch1 > 0 ? 2 : 1); ph++) ab_fir_wave2<NS>(p, pkt0, w, lane, sh, ph, ph ? nch1 : nch0);
+        }
+    } else if constexpr (P == 16) {
         __builtin_amdgcn_s_setprio(1);   // above the output waves, below the entropy waves (8192 packets: 1.074 -> 1.048 ms, cfg3 3.33 -> 3.25)
         for (int ph = 0; ph < (nch1 > 0 ? 2 : 1); ph++) ab_fir16_wave(p, pkt0, role - 2, lane, sh, ph, ph ? nch1 : nch0);
     } else {
         __builtin_amdgcn_s_setprio(1);   // above the output waves, below the entropy waves (8192 packets: 1.074 -> 1.048 ms, cfg3 3.33 -> 3.25)
         if (__builtin_expect(!wide, 1)) {
-            for (int ph = 0; ph < (nch1 > 0 ? 2 : 1); ph++) ab_fir_wave(p, pkt0, lane, sh, ph, ph ? nch1 : nch0);
+            for (int ph = 0; ph < (nch1 > 0 ? 2 : 1); ph++) ab_fir_wave<NS>(p, pkt0, 0, lane, sh, ph, ph ? nch1 : nch0);
         } else {
-            for (int ph = 0; ph < (nch1 > 0 ? 2 : 1); ph++) ab_fir_wave2(p, pkt0, lane, sh, ph, ph ? nch1 : nch0);
+            for (int ph = 0; ph < (nch1 > 0 ? 2 : 1); ph++) ab_fir_wave2<NS>(p, pkt0, 0, lane, sh, ph, ph ? nch1 : nch0);
         }
     }
 }
@@ -877,3 +944,8 @@ __device__ __forceinline__ void ab_kernel_body(const alac_decode_params& p) {
 extern "C" __global__ __launch_bounds__(256, 5) void alac_decode_ab_kernel(alac_decode_params p) { ab_kernel_body<8>(p); }
 // LPC orders up to 31 (and the delta mode): two FIR waves in the 16-lane layout with two tap registers, four packets each
 extern "C" __global__ __launch_bounds__(256) void alac_decode_ab32_kernel(alac_decode_params p) { ab_kernel_body<16>(p); }
+// The main kernel's dense arrangement for big batches: 16 packets per 256-thread workgroup: one entropy wave for all 16
+// streams (4 lanes each), one output wave for all 16, two FIR waves of 8 streams -- one wave per SIMD, roles by SIMD and turn
+// as above.  Same results, about a fifth fewer instructions per sample; a step of its entropy wave takes as long as the
+// 8-stream one's, so small (latency-bound) batches gain nothing.
+extern "C" __global__ __launch_bounds__(256, 4) void alac_decode_ab_dense_kernel(alac_decode_params p) { ab_kernel_body<8, 16>(p); }

@@ -12,7 +12,8 @@ pytestmark = pytest.mark.gpu
 def torch():
     import torch as t
 
-    assert t.cuda.is_available()
+    assert t.cuda.device_count() > 0
+    t.cuda.set_device(0)
     return t
 
 

@@ -19,6 +19,18 @@ def pkg():
     return p
 
 
+@pytest.fixture(autouse=True, params=["auto", "dense"])
+def arrangement(request, monkeypatch):
+    """Every test of this module runs twice: with the library's own choice between the main kernel's two arrangements
+    (8 packets per workgroup below 12289 packets per batch) and with the 16-packet ("dense") arrangement forced
+    (ALACGPU_DENSE is read when a context is created)."""
+    if request.param == "dense":
+        monkeypatch.setenv("ALACGPU_DENSE", "1")
+    else:
+        monkeypatch.delenv("ALACGPU_DENSE", raising=False)
+    return request.param
+
+
 def run_both(pkg, oracle, b, n_threads=8):
     with pkg.AlacGpuContext(b["stream_cfgs"], device=0) as ctx:
         g = ctx.decode_batch(b["blob"], b["offsets"], b["sizes"], b["cfg_idx"], b["slot_ints"])
