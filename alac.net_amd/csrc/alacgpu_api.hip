@@ -323,16 +323,19 @@ int alacgpu_dbg_decode_batch_device_stamps(alacgpu_ctx* ctx, const void* d_blob,
     return launch(ctx, p, (hipStream_t)hip_stream);
 }
 
-// Host buffers: the batch is cut into up to four contiguous packet ranges, each on its own stream, so that the H2D copy of
-// range k+1, the decode of range k and the D2H copy of range k-1 overlap (the two copy directions use different DMA
-// engines).  Issue order: all uploads and launches first, then the downloads in range order.
+// Host buffers: the batch is cut into contiguous packet ranges (two by default, up to four), each on its own stream, so that
+// the H2D copy of range k+1, the decode of range k and the D2H copy of range k-1 overlap (the two copy directions use
+// different DMA engines).  Issue order: all uploads and launches first, then the downloads in range order.
 int alacgpu_decode_batch(alacgpu_ctx* ctx, const uint8_t* blob, uint64_t blob_bytes, const uint64_t* offsets,
                          const uint32_t* sizes, const uint16_t* cfg_idx, uint32_t n_packets, int32_t* pcm_out,
                          uint32_t slot_ints, int32_t* out_bytes, int32_t* out_samples, int32_t* status) {
     if (!ctx) return ALACGPU_ERR_BAD_ARG;
     if (n_packets == 0) return ALACGPU_OK;
     if (!blob || !offsets || !sizes || !pcm_out || !status || slot_ints == 0) return ALACGPU_ERR_BAD_ARG;
-    int nch = ctx->host_chunks ? ctx->host_chunks : (n_packets >= 2048u ? 4 : n_packets >= 512u ? 2 : 1);
+    // measured on cfg2 (4096 packets, tools/host_path_rate.py): 1 / 2 / 4 ranges = 4.20 / 3.97 / 4.05 ms with int32 output,
+    // 2.99 / 2.63 / 3.21 ms packed: the link runs at 55 GB/s either way (134 MiB of int32 PCM alone are 2.5 ms), the copies
+    // from and to ordinary memory block the issuing thread, and a range's decode takes as long as the whole batch's
+    int nch = ctx->host_chunks ? ctx->host_chunks : (n_packets >= 1024u ? 2 : 1);
     nch = std::min<int>(nch, (int)n_packets);
     // validate, and find the blob range every chunk needs
     uint32_t lo[N_HOST_STREAMS + 1];
