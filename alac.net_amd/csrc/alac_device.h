@@ -240,9 +240,11 @@ __device__ __forceinline__ int rice_step(Rice& s, const RiceCfg& c, int remainin
 // reads are address-masked, nothing else is touched).
 // WANT_R: return the residual (else 0).  RAW: return the unsigned code value dv instead of the signed residual
 // (dv >> 1) ^ -(dv & 1) (:225-226) -- a consumer with cycles to spare does that conversion itself (fir8_step<.., true>).
+// It does not apply the history clamp for values above 0xFFFF either (:229; two instructions): it tracks the largest value
+// in vmax instead, and the caller sends a unit with vmax > 0xFFFF to the escape tier, whose step does clamp.
 template <bool WANT_R, bool RAW = false>
 __device__ __forceinline__ int rice_spec_step(Rice& s, const RiceCfg& c, uint32_t ring, uint32_t& xmax,
-                                              int& hmin) {
+                                              int& hmin, uint32_t& vmax) {
     const uint32_t win = rice_window(s);
     const uint32_t x = (uint32_t)__builtin_clz(~win | 0x00400000u);          // leading ones, capped at 9 (:196)
     xmax = max(xmax, x);
@@ -251,13 +253,12 @@ __device__ __forceinline__ int rice_spec_step(Rice& s, const RiceCfg& c, uint32_
     const uint32_t e = __builtin_amdgcn_ubfe(win, (uint32_t)(31 - k) - x, (uint32_t)k);  // Readbits(k) (:205)
     const uint32_t m = __builtin_amdgcn_ubfe(0xFFFFFFFFu, 0u, (uint32_t)k);        // (1 << k) - 1
     const uint32_t v = __umul24(x, m) + (e > 1u ? e - 1u : 0u);                    // :206-208
+    vmax = max(vmax, v);
     const uint32_t cur2 = s.cur - (x + (uint32_t)k) - (e > 1u ? 1u : 0u);    // bits used: x+1+k, minus the un-read one (:210)
     int r = 0;
     if (WANT_R) r = RAW ? (int)v : (int)(v >> 1) ^ -(int)(v & 1u);           // :225-226
     const int h = s.hist;
-    int hx = (int)(__umul24(v, (uint32_t)c.hist_mult) + (uint32_t)h) - (wmul(h, c.hist_mult) >> 9);
-    asm volatile("" : "+v"(hx));   // keep this unconditional: a select, not an exec-masked branch
-    const int hn = (int)v > 0xFFFF ? 0xFFFF : hx;                            // :229
+    const int hn = (int)(__umul24(v, (uint32_t)c.hist_mult) + (uint32_t)h) - (wmul(h, c.hist_mult) >> 9);   // :229 without the clamp
     hmin = min(hmin, hn);
     const uint32_t a2 = rice_w2_addr(cur2, ring);
     const bool adv = a2 != s.ra;

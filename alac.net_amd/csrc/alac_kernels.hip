@@ -93,24 +93,38 @@ __device__ __forceinline__ void spec_unpark(Rice& rs, const Rice& snap, bool par
     }
 }
 
+// Diagnostic builds (make diag: -DALAC_DIAG) count what the units of a workgroup's entropy wave did; the counts go to the
+// stamp slots of the diagnostic entry point (tools/stamps.py).  Nothing of this exists in the product build.
+struct SpecStats {
+#ifdef ALAC_DIAG
+    int plain_ok = 0, fail_esc = 0, fail_run = 0, z_units = 0, esc_units = 0, full_units = 0, late_run = 0, redo = 0;
+#endif
+};
+#ifdef ALAC_DIAG
+#define SPEC_COUNT(field) (st.field++)
+#else
+#define SPEC_COUNT(field) ((void)0)
+#endif
+
 template <bool WANT_R, int QSTRIDE, bool RAW = false>
-__device__ __forceinline__ bool spec_unit(Rice& rs, int& full_left, const RiceCfg& c, uint32_t ring, int* q) {
+__device__ __forceinline__ bool spec_unit(Rice& rs, int& full_left, const RiceCfg& c, uint32_t ring, int* q, SpecStats& st) {
     const Rice snap = rs;
     // A stream whose zero run covers the whole unit is PARKED: its lanes run the plain code with everybody else (on
     // whatever their window shows -- harmless, see rice_spec_step), are left out of the unit's verdict and get their state
     // back afterwards, minus SPEC_UNIT zeros: one silent stream does not keep the other seven on tier 2.
     const bool parked = rs.zrun >= SPEC_UNIT;
     const bool special = __builtin_amdgcn_ballot_w64(rs.nforce == 0u && !parked) != 0;
-    uint32_t xmax = 0;
+    uint32_t xmax = 0, vmax = 0;
     int hmin = 0x7FFFFFFF;
     if (full_left == 0) {
         if (!special) {
 #pragma unroll
             for (int ii = 0; ii < SPEC_UNIT; ii++) {
-                const int r = rice_spec_step<WANT_R, RAW>(rs, c, ring, xmax, hmin);
+                const int r = rice_spec_step<WANT_R, RAW>(rs, c, ring, xmax, hmin, vmax);
                 if (WANT_R) q[ii * QSTRIDE] = r;
             }
             spec_unpark<WANT_R, QSTRIDE>(rs, snap, parked, xmax, hmin, q);
+            vmax = parked ? 0u : vmax;
         } else {
 #pragma unroll
             for (int ii = 0; ii < SPEC_UNIT; ii++) {
@@ -120,10 +134,12 @@ __device__ __forceinline__ bool spec_unit(Rice& rs, int& full_left, const RiceCf
             rs.nforce = (rs.zrun > 0 || rs.signmod != 0) ? 0u : 0xFFFFFFFFu;
         }
         const bool newrun = __builtin_amdgcn_ballot_w64(hmin < 128) != 0;
-        const bool sawesc = __builtin_amdgcn_ballot_w64(xmax > 8u) != 0;
-        if (__builtin_expect(!newrun && !sawesc, 1)) return true;
+        // an escape code -- or a value whose history update needs the clamp the plain step leaves out
+        const bool sawesc = __builtin_amdgcn_ballot_w64(xmax > 8u || vmax > 0xFFFFu) != 0;
+        if (__builtin_expect(!newrun && !sawesc, 1)) { if (special) SPEC_COUNT(z_units); else SPEC_COUNT(plain_ok); return true; }
         rs = snap;
-        if (newrun) return false;          // no tier can do it
+        if (newrun) { SPEC_COUNT(fail_run); return false; }          // no tier can do it
+        SPEC_COUNT(fail_esc);
         full_left = 1;                     // escapes: go on with an escape-capable tier
         xmax = 0;
         hmin = 0x7FFFFFFF;
@@ -137,6 +153,7 @@ __device__ __forceinline__ bool spec_unit(Rice& rs, int& full_left, const RiceCf
         spec_unpark<WANT_R, QSTRIDE>(rs, snap, parked, xmax, hmin, q);
         const bool sawesc = __builtin_amdgcn_ballot_w64(xmax > 8u) != 0;
         full_left = sawesc ? ESC_HOLD : full_left - 1;
+        SPEC_COUNT(esc_units);
     } else if (!special) {                 // tier 1E for wide raw values (24-bit streams)
         uint32_t w3 = lds_load(((rs.ra + 4u) & RING_MASK) | ring);
 #pragma unroll
@@ -147,6 +164,7 @@ __device__ __forceinline__ bool spec_unit(Rice& rs, int& full_left, const RiceCf
         spec_unpark<WANT_R, QSTRIDE>(rs, snap, parked, xmax, hmin, q);
         const bool sawesc = __builtin_amdgcn_ballot_w64(xmax > 8u) != 0;
         full_left = sawesc ? ESC_HOLD : full_left - 1;
+        SPEC_COUNT(esc_units);
     } else {                               // tier 3
         uint32_t w3 = lds_load(((rs.ra + 4u) & RING_MASK) | ring);
 #pragma unroll
@@ -157,9 +175,11 @@ __device__ __forceinline__ bool spec_unit(Rice& rs, int& full_left, const RiceCf
         rs.nforce = (rs.zrun > 0 || rs.signmod != 0) ? 0u : 0xFFFFFFFFu;
         const bool sawesc = __builtin_amdgcn_ballot_w64(xmax > 8u) != 0;
         full_left = sawesc ? FULL_HOLD : full_left - 1;
+        SPEC_COUNT(full_units);
     }
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(hmin < 128) != 0, 0)) {
         rs = snap;
+        SPEC_COUNT(late_run);
         return false;
     }
     return true;
@@ -222,6 +242,7 @@ __device__ __forceinline__ uint32_t ab_entropy_pass(const alac_decode_params& p,
     const int n_row = stream_on ? m.n : 0;
     int flags = 0;
     int full_left = 0;
+    SpecStats st;
     Rice rs;
     rs.w0 = rs.w1 = rs.w2 = 0; rs.next = 12; rs.hist = 0; rs.signmod = 0; rs.zrun = 0; rs.nforce = 0;
     rs.ra = rs.ra_sync = lds_addr(sh.rings[g]);
@@ -316,8 +337,9 @@ __device__ __forceinline__ uint32_t ab_entropy_pass(const alac_decode_params& p,
                 if (fast_chunk) {
 #pragma unroll
                     for (int u = 0; u < AB_CHUNK; u += SPEC_UNIT) {
-                        const bool redo = !spec_unit<true, S, RAW>(rs, full_left, kc, kring, q + u * S);
+                        const bool redo = !spec_unit<true, S, RAW>(rs, full_left, kc, kring, q + u * S, st);
                         if (redo) {
+                            SPEC_COUNT(redo);
                             for (int ii = 0; ii < SPEC_UNIT; ii++) {
                                 const int r = rice_step(rs, kc, kn - 1 - (i0 + u + ii), i0 + u + ii, &flags, kring);
                                 q[(u + ii) * S] = RAW ? ab_zigzag(r) : r;
@@ -340,6 +362,15 @@ __device__ __forceinline__ uint32_t ab_entropy_pass(const alac_decode_params& p,
         }
     }
     wg_sync();      // final barrier of the pass (every wave executes nchunks + 1 per pass)
+#ifdef ALAC_DIAG
+    if (p.dbg && lane == 0 && NS == 8) {   // slot 1: plain ok | escape failures; 4: z units | escape-tier units; 5: run failures | redone; 6: full | late run
+        unsigned long long* d = p.dbg + 8 * blockIdx.x;
+        d[1] += ((unsigned long long)st.plain_ok << 32) | (unsigned)st.fail_esc;
+        d[4] += ((unsigned long long)st.z_units << 32) | (unsigned)st.esc_units;
+        d[5] += ((unsigned long long)st.fail_run << 32) | (unsigned)st.redo;
+        d[6] += ((unsigned long long)st.full_units << 32) | (unsigned)st.late_run;
+    }
+#endif
     rice_sync(rs);
     *flags_out = stream_on ? (ended ? endflags : flags) : 0;
     return ended ? endpos : rice_bitpos(rs);
@@ -374,7 +405,9 @@ __device__ __forceinline__ void ab_entropy_wave(const alac_decode_params& p, uin
                                              compressed && (ph == 0 || m.stereo), g, sub, lane, ph ? nch1 : nch0, &fl);
         if (ph == 0) { end_a = end_b = end; flags_a = fl; }
         else { end_b = end; flags_b = fl; }
+#ifndef ALAC_DIAG
         if (p.dbg && lane == 0 && ph == 0) p.dbg[8 * blockIdx.x + 1] = clock64();
+#endif
     }
     // ---- status, in the reference's control-flow order (same as the other kernels / the oracle) ----
     if (valid && sub == 0) {
@@ -868,9 +901,11 @@ __device__ __forceinline__ void ab_kernel_body(const alac_decode_params& p) {
     const int nch1 = (__builtin_amdgcn_readfirstlane(wave_max(n1)) + AB_CHUNK - 1) / AB_CHUNK;
     for (int t = threadIdx.x; t < AB_CHUNK * NS; t += blockDim.x) (&sh.zeros[0][0])[t] = 0;
     if (p.dbg && lane == 0) {   // diagnostic (ALACGPU_DEBUG_STAMPS): where each wave runs, when the workgroup starts
-        const unsigned hw = __builtin_amdgcn_s_getreg(63492), xcc = __builtin_amdgcn_s_getreg(63508);
         if (wave == 0) {
+#ifndef ALAC_DIAG
+            const unsigned hw = __builtin_amdgcn_s_getreg(63492), xcc = __builtin_amdgcn_s_getreg(63508);
             p.dbg[8 * blockIdx.x + 4] = ((unsigned long long)xcc << 32) | hw;
+#endif
             p.dbg[8 * blockIdx.x + 0] = clock64();
         }
     }
@@ -882,9 +917,11 @@ __device__ __forceinline__ void ab_kernel_body(const alac_decode_params& p) {
     // for that, which leaves at once), takes its turn k on the CU from a counter, and puts entropy on SIMD k, output on
     // k + 1, FIR on k + 2 (the 32-tap kernel: its FIR waves on k + 2 and k + 3).  Workgroups with consecutive turns so
     // never pair two heavy waves; four per CU load every SIMD alike.
+#ifndef ALAC_DIAG
     if (p.dbg && lane == 0 && wave < 3)
         p.dbg[8 * blockIdx.x + (wave == 0 ? 3 : wave == 1 ? 5 : 6)] =
             ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492);
+#endif
     int role = wave;
     if (p.cu_arrivals) {
         const uint32_t hw = __builtin_amdgcn_s_getreg(63492);                       // HW_ID
