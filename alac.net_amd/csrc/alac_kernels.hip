@@ -334,6 +334,11 @@ __device__ __forceinline__ uint32_t ab_entropy_pass(const alac_decode_params& p,
             int* q = (sub == 0 && kreal) ? &sh.resq[c & 1][0][g] : &sh.dummy[lane];
             if (i0 < nmax) {
                 const bool fast_chunk = i0 + AB_CHUNK <= knmin - 1;
+#if defined(ALAC_EXPERIMENT) && ALAC_EXPERIMENT == 2
+                if (fast_chunk) {
+                    for (int u = 0; u < AB_CHUNK; u++) q[u * S] = 0;
+                } else
+#endif
                 if (fast_chunk) {
 #pragma unroll
                     for (int u = 0; u < AB_CHUNK; u += SPEC_UNIT) {
@@ -475,7 +480,11 @@ __device__ __forceinline__ void ab_fir_wave(const alac_decode_params& p, uint32_
 #pragma unroll
         for (int half = 0; half < AB_CHUNK / 8; half++) {
             const int ih = i0 + 8 * half;
+#if defined(ALAC_EXPERIMENT) && ALAC_EXPERIMENT == 1
+            if (false) {
+#else
             if (ih < nmax) {
+#endif
                 if (ih > 8 && clean) {
                     int err = q[(8 * half) * S];
 #pragma unroll
