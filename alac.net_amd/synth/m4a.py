@@ -18,9 +18,15 @@ def alac_specific_config(frame_len, sample_size, pb, mb, kb, channels, sample_ra
 
 
 def write_m4a(packets, durations, frame_len=4096, sample_size=16, channels=2, sample_rate=44100, pb=40, mb=10, kb=14,
-              packets_per_chunk=5, mdat_first=False):
-    """Returns the file as bytes.  durations[i] = PCM frames in packet i."""
+              packets_per_chunk=5, mdat_first=False, uniform_stsz=False, extra_atoms=False):
+    """Returns the file as bytes.  durations[i] = PCM frames in packet i.
+    uniform_stsz: every packet is zero-padded to the longest one's size and stsz carries that one size (QTMovieT.cs:575-590).
+    extra_atoms: adds the atoms the reference skips -- a top-level `free`, `udta` and `free` inside moov, `edts` inside trak
+    (QTMovieT.cs:95-102, :135-177, :668-722)."""
     n = len(packets)
+    if uniform_stsz:
+        size = max(len(p) for p in packets)
+        packets = [p + bytes(size - len(p)) for p in packets]
     cfg = alac_specific_config(frame_len, sample_size, pb, mb, kb, channels, sample_rate)
     inner = _atom("alac", struct.pack(">I", 0) + cfg)                       # size, 'alac', version/flags, config
     entry = (bytes(6) + struct.pack(">HHIH", 1, 0, 0, 0) + struct.pack(">HH", channels, sample_size)
@@ -35,7 +41,10 @@ def write_m4a(packets, durations, frame_len=4096, sample_size=16, channels=2, sa
             runs.append([1, d])
     assert len(runs) <= 16, "the reference's TimeToSample table has 16 entries"
     stts = _atom("stts", struct.pack(">II", 0, len(runs)) + b"".join(struct.pack(">II", c, d) for c, d in runs))
-    stsz = _atom("stsz", struct.pack(">III", 0, 0, n) + b"".join(struct.pack(">I", len(p)) for p in packets))
+    if uniform_stsz:
+        stsz = _atom("stsz", struct.pack(">III", 0, len(packets[0]), n))
+    else:
+        stsz = _atom("stsz", struct.pack(">III", 0, 0, n) + b"".join(struct.pack(">I", len(p)) for p in packets))
     n_chunks = (n + packets_per_chunk - 1) // packets_per_chunk
     stsc_entries = [(1, packets_per_chunk, 1)]
     if n % packets_per_chunk and n_chunks > 1:
@@ -56,11 +65,15 @@ def write_m4a(packets, durations, frame_len=4096, sample_size=16, channels=2, sa
         mdhd = _atom("mdhd", struct.pack(">IIIIIHH", 0, 0, 0, sample_rate, sum(durations), 0, 0))
         mdia = _atom("mdia", mdhd + hdlr + minf)
         tkhd = _atom("tkhd", bytes(84))
-        trak = _atom("trak", tkhd + mdia)
+        edts = _atom("edts", _atom("elst", struct.pack(">IIIII", 0, 1, sum(durations), 0, 0x00010000))) if extra_atoms else b""
+        trak = _atom("trak", tkhd + edts + mdia)
         mvhd = _atom("mvhd", bytes(100))
-        return _atom("moov", mvhd + trak)
+        extra = (_atom("udta", _atom("meta", bytes(20))) + _atom("free", bytes(37))) if extra_atoms else b""
+        return _atom("moov", mvhd + trak + extra)
 
     ftyp = _atom("ftyp", b"M4A " + struct.pack(">I", 0) + b"M4A mp42isom")
+    if extra_atoms:
+        ftyp += _atom("free", bytes(11))
     mdat = _atom("mdat", b"".join(packets))
     if mdat_first:
         moov = build(len(ftyp))

@@ -40,6 +40,20 @@ def test_demuxer_tables(synth):
     assert data[res.Stco[0]: res.Stco[0] + len(packets[0])] == packets[0]
 
 
+def test_demuxer_uniform_stsz_and_skipped_atoms(synth):
+    # the stsz form with one size for every packet (QTMovieT.cs:575-590) and the atoms the reference skips:
+    # top-level free, moov/udta, moov/free, trak/edts (QTMovieT.cs:95-102, :135-177, :668-722)
+    from alac.net_amd import container
+
+    data, packets, pcm, d = make_file(synth, n_packets=12, last=4096, uniform_stsz=True, extra_atoms=True)
+    res = container.DemuxResT()
+    assert container.QtMovieT(container._Stream(io.BytesIO(data)), res).ReadHeader() == container.MDAT_OK
+    size = max(len(p) for p in packets)
+    assert res.SampleByteSize.tolist() == [size] * 12 and res.MdatLen == 12 * size
+    assert res.TimeToSample == [(12, 4096)] and res.Stsc == [(1, 5, 1), (3, 2, 1)]
+    assert data[res.Stco[1]: res.Stco[1] + len(packets[5])] == packets[5]      # chunk 2 starts at packet 5
+
+
 def test_mdat_before_moov_is_rejected_like_the_reference(synth):
     # QTMovieT.cs:746 compares Seek()'s return value (the new position) with 0 -> such files never load
     from alac.net_amd import container
@@ -78,6 +92,25 @@ def test_alaccontext_read_loop_equals_source_pcm(synth, sample_size, stereo):
     bps = sample_size // 8
     exp = b"".join(int(v).to_bytes(4, "little", signed=True)[:bps] for v in pcm)
     assert bytes(out) == exp
+
+
+@pytest.mark.gpu
+def test_alaccontext_reads_uniform_stsz_file_with_skipped_atoms(synth):
+    from alac.net_amd import container
+
+    data, packets, pcm, d = make_file(synth, n_packets=12, last=4096, uniform_stsz=True, extra_atoms=True)
+    with container.AlacContext(io.BytesIO(data), batch_packets=5) as ctx:
+        buf = np.zeros(1024 * 80, dtype=np.uint8)
+        out = bytearray()
+        while True:
+            n = ctx.Read(buf)
+            if n <= 0:
+                break
+            out += bytes(buf[:n])
+        ctx.SetPosition(4096 * 7 + 5)          # a packet in the second chunk: offsets from stco + the uniform size
+        n = ctx.Read(buf)
+        assert bytes(buf[:n]) == pcm[(4096 * 7 + 5) * 2: 4096 * 8 * 2].astype("<i2").tobytes()
+    assert bytes(out) == pcm.astype("<i2").tobytes()
 
 
 @pytest.mark.gpu
