@@ -302,6 +302,9 @@ class AlacFile:
         ref, out_bytes, st = self._ctx.decode_frame(0, inbuffer)
         if st == ST_UNSUPPORTED_ELEMENT:
             return out_bytes  # reference decodes nothing and still returns outputsize (:437,:577,:718)
+        if (st == ST_UNSUPPORTED_SAMPLE_SIZE and len(inbuffer) and (int(inbuffer[0]) >> 5) == 1
+                and int(self._cfg[0]["sample_size"]) not in (20, 32)):
+            return out_bytes  # a two-channel element of any other sample size: nothing is written, no exception (:701-716)
         if st == ST_UNSUPPORTED_PREDTYPE and len(inbuffer) and (int(inbuffer[0]) >> 5) == 0:
             # one-channel element with an unknown prediction type: the reference skips the predictor silently and hands
             # out whatever its buffer held (AlacFile.cs:484-496); here the caller's buffer is left as it was

@@ -376,6 +376,9 @@ class AlacContext:
         # buffer without throwing (AlacFile.cs:484-496); here: silence of the same length (status 1 = nothing decoded)
         first = blob[np.minimum(offsets, max(len(blob) - 1, 0)).astype(np.int64)] if len(blob) else np.zeros(len(sizes), np.uint8)
         st = np.where((st == 3) & ((first >> 5) == 0) & (sizes > 0), 1, st).astype(np.int32)
+        # a two-channel element in a stream whose sample size is neither 16 / 24 nor 20 / 32: nothing written, no exception (:701-716)
+        if int(self._cfg[0]["sample_size"]) not in (16, 24, 20, 32):
+            st = np.where((st == 2) & ((first >> 5) == 1) & (sizes > 0), 1, st).astype(np.int32)
         return pcm, ob, os_, st, np.array(durs)
 
     def _raise_for(self, st):

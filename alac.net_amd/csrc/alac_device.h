@@ -820,10 +820,12 @@ __device__ __forceinline__ Meta parse_meta(const alac_decode_params& p, uint32_t
         else if (channels > 1) { m.status = ALACGPU_ST_UNSUPPORTED_ELEMENT_D; m.n = (int)cfg.max_samples_per_frame;
                                  m.out_bytes = (int)((uint32_t)m.n * (uint32_t)bytespersample); }
         else if (m.ss != 16 && m.ss != 24) m.status = ALACGPU_ST_UNSUPPORTED_SAMPLE_SIZE_D;
-        else if (m.stereo && m.nc < 2) m.status = ALACGPU_ST_UNSUPPORTED_ELEMENT_D;
         else if (m.nc < 1 || m.nc > 2) m.status = ALACGPU_ST_UNSUPPORTED_ELEMENT_D;
         else if (m.n <= 0 || m.n > BUFFER_SIZE || (uint64_t)m.n * (uint64_t)m.nc > p.slot_ints)
             m.status = ALACGPU_ST_BAD_SAMPLE_COUNT_D;
+        // a two-channel element in a one-channel stream comes out as its left channel (AlacFile.cs:353-354 with numchannels == 1:
+        // every right sample is overwritten by the next left one); channel A is parked in the slot, which needs room for it
+        else if (m.stereo && m.nc < 2 && (uint64_t)m.n * 2u > p.slot_ints) m.status = ALACGPU_ST_UNSUPPORTED_ELEMENT_D;
         else if (m.ss - m.ub * 8 < 8) m.status = ALACGPU_ST_UNSUPPORTED_PARAMS_D;
         m.rawbit = hdr_end;
         if (m.status == 0) {

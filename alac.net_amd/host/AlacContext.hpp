@@ -302,6 +302,10 @@ public:
                 // a one-channel element with an unknown prediction type: the reference decodes nothing and hands out its
                 // stale buffer without throwing (AlacFile.cs:484-496); here: silence of the same length
                 if (pk.status == ALACGPU_ST_UNSUPPORTED_PREDTYPE && firstByte_[(size_t)p] >> 5 == 0) pk.status = ALACGPU_ST_UNSUPPORTED_ELEMENT;
+                // a two-channel element of a sample size other than 16 / 24 and 20 / 32: nothing written, no exception (:701-716)
+                if (pk.status == ALACGPU_ST_UNSUPPORTED_SAMPLE_SIZE && firstByte_[(size_t)p] >> 5 == 1 && cfg_.sample_size != 20 &&
+                    cfg_.sample_size != 32)
+                    pk.status = ALACGPU_ST_UNSUPPORTED_ELEMENT;
                 size_t cnt = pk.status == ALACGPU_ST_OK ? (size_t)pk.samples * cfg_.num_channels : 0;
                 pk.pcm.assign(pcm.begin() + (size_t)p * slot, pcm.begin() + (size_t)p * slot + cnt);
                 ready_.push_back(std::move(pk));

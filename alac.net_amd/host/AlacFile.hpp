@@ -44,6 +44,10 @@ public:
         // a one-channel element with an unknown prediction type: the reference skips the predictor silently and hands out
         // whatever its buffer held (AlacFile.cs:484-496); here the caller's buffer is left as it was
         if (status == ALACGPU_ST_UNSUPPORTED_PREDTYPE && in_bytes > 0 && (inbuffer[0] >> 5) == 0) return out_bytes;
+        // a two-channel element of a sample size other than 16 / 24 (decoded) and 20 / 32 (throw): nothing written (:701-716)
+        if (status == ALACGPU_ST_UNSUPPORTED_SAMPLE_SIZE && in_bytes > 0 && (inbuffer[0] >> 5) == 1 && cfg_.sample_size != 20 &&
+            cfg_.sample_size != 32)
+            return out_bytes;
         throw_for(status);
         return out_bytes;  // AlacFile.cs:718
     }

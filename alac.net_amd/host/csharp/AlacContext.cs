@@ -170,7 +170,10 @@ namespace ALACdotNET.Decoder
             // one-channel element with an unknown prediction type: the reference decodes nothing and hands out its stale
             // buffer (AlacFile.cs:484-496); here: silence of the same length
             bool staleMono = status == AlacGpuNative.StUnsupportedPredType && (_blob[(long)_offsets[p]] >> 5) == 0;
-            if (!staleMono) _alac.ThrowFor(status);
+            // a two-channel element of a sample size other than 16 / 24 and 20 / 32: nothing written, no exception (AlacFile.cs:701-716)
+            bool silentStereo = status == AlacGpuNative.StUnsupportedSampleSize && (_blob[(long)_offsets[p]] >> 5) == 1 &&
+                                _alac.Config.SampleSize != 20 && _alac.Config.SampleSize != 32;
+            if (!staleMono && !silentStereo) _alac.ThrowFor(status);
             int bps = GetBytesPerSample();
             int outputBytes = _outBytes[p] - _offset * bps;               // :200
             // :201 drops _offset INTS of the reference's buffer: 16-bit streams hold a sample per int (2 bytes each),

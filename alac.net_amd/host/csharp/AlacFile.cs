@@ -40,6 +40,9 @@ namespace ALACdotNET.Decoder
             // a one-channel element with an unknown prediction type: the reference skips the predictor silently and hands
             // out whatever its buffer held (AlacFile.cs:484-496); here the caller's buffer is left as it was
             if (status == AlacGpuNative.StUnsupportedPredType && (inbuffer[0] >> 5) == 0) return outBytes;
+            // a two-channel element of a sample size other than 16 / 24 (decoded) and 20 / 32 (throw): nothing is written (:701-716)
+            if (status == AlacGpuNative.StUnsupportedSampleSize && (inbuffer[0] >> 5) == 1 && _cfg.SampleSize != 20 && _cfg.SampleSize != 32)
+                return outBytes;
             ThrowFor(status);
             return outBytes;
         }

@@ -353,10 +353,14 @@ static int decode_frame_impl(const alac_oracle_cfg* cfg, scratch_t* s, const uin
     /* The switch on sample size comes last in the reference (:527,:701); nothing before it has a
      * visible effect, so it is checked first here. */
     if (sampleSize != 16 && sampleSize != 24) return ALAC_ORACLE_UNSUPPORTED_SAMPLE_SIZE;
-    if (stereo && numchannels < 2) return ALAC_ORACLE_UNSUPPORTED_ELEMENT; /* overlapping writes, not a real stream */
     if (numchannels < 1 || numchannels > 2) return ALAC_ORACLE_UNSUPPORTED_ELEMENT;
     if (outputsamples <= 0 || outputsamples > BUFFER_SIZE || (size_t)outputsamples * (size_t)numchannels > cap)
         return ALAC_ORACLE_BAD_SAMPLE_COUNT;
+    /* A two-channel element in a one-channel stream: Deinterlace16/24 write out[i] = left, out[i + 1] = right with
+     * numchannels == 1 (:353-354, :390-395), so every right sample is overwritten by the next left one and the frame comes
+     * out as its LEFT channel (plus one stray int at out[n]).  Reproduced when the slot has room for two channels (the GPU
+     * path parks channel A there); otherwise reported as an unsupported element. */
+    if (stereo && numchannels < 2 && (size_t)outputsamples * 2 > cap) return ALAC_ORACLE_UNSUPPORTED_ELEMENT;
     if (sampleSize - uncompressedBytes * 8 < 8) return ALAC_ORACLE_UNSUPPORTED_PARAMS;
 
     int32_t readsamplesize = sampleSize - (uncompressedBytes * 8) + (stereo ? 1 : 0); /* :454,:596 */

@@ -135,6 +135,10 @@ def main():
         # 16-bit stereo, shift bytes present (ub = 1): Deinterlace16 ignores them after reading them (:634-641, :705)
         (0, pack([(3, 1), (4, 0), (12, 0), (1, 1), (2, 1), (1, 0), (32, 2), (8, 0), (8, 0), (4, 0), (4, 0), (3, 4), (5, 0),
                   (4, 0), (4, 0), (3, 4), (5, 0), (8, 0x11), (8, 0x22), (8, 0x33), (8, 0x44), "110", "0", "10", "0", "0", "0"], slack=4)),
+        # a two-channel element in a one-channel stream (cfg 2): out[i] = left, out[i + 1] = right (:353-354) -> the left channel
+        (2, pack([(3, 1), (4, 0), (12, 0), (1, 1), (2, 0), (1, 0), (32, 1), (8, 8), (8, 200), (4, 0), (4, 0), (3, 4), (5, 0),
+                  (4, 0), (4, 0), (3, 4), (5, 0), (9, 0x1FF), (17, 200), (9, 0x1FF), (17, 20)], slack=4)),
+        (2, pack([(3, 1), (4, 0), (12, 0), (1, 1), (2, 0), (1, 1), (32, 3), (16, 5), (16, 6), (16, 0xFFF0), (16, 8), (16, 9), (16, 10)], slack=4)),
     ]
     for c, pk in hand:
         packets.append(pk)

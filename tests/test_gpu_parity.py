@@ -559,6 +559,16 @@ def test_hand_kats_round2_on_gpu(pkg):
     assert pcm[1, :2].tolist() == [0x123456, -2] and ob[1] == 6
     assert pcm[2, :2].tolist() == [35000, -3] and ob[2] == 6
     assert pcm[3, :5].tolist() == [0, 0, 0, 0, -1] and ob[3] == 10 and os_[3] == 5
+    # KAT-17: a two-channel element in a one-channel stream comes out as its left channel (AlacFile.cs:353-354)
+    esc = pack([(3, 1), (4, 0), (12, 0), (1, 1), (2, 0), (1, 1), (32, 2), (16, 0x0001), (16, 0xFFFF), (16, 0x7FFF), (16, 0x8000)])
+    pk = [kat_q3_packet(), esc]
+    blob = np.frombuffer(b"".join(pk), dtype=np.uint8)
+    sizes = np.array([len(x) for x in pk], dtype=np.uint32)
+    offsets = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.uint64)
+    with pkg.AlacGpuContext([(4096, 16, 40, 10, 14, 1)]) as ctx:
+        pcm, ob, os_, st = ctx.decode_batch(blob, offsets, sizes, None, 64)
+    assert st.tolist() == [0, 0] and ob.tolist() == [2, 4]
+    assert pcm[0, :1].tolist() == [103] and pcm[1, :2].tolist() == [1, 32767]
 
 
 def test_mono_element_with_unknown_prediction_type_does_not_throw(pkg, synth):

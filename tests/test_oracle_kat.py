@@ -201,3 +201,15 @@ def test_kat16_order20_fir_both_signs(oracle):
     out, coef = oracle.predictor(err, 16, coefs, 2)
     assert out.tolist() == list(range(1, 22)) + [5, 4]
     assert coef.tolist() == [0] * 16 + [1, 1, 0, 4]
+
+
+def test_kat17_two_channel_element_in_a_one_channel_stream(oracle):
+    # AlacFile.cs:353-354 with numchannels == 1: out[i] = left, out[i + 1] = right -- every right sample is overwritten by
+    # the next left one: the frame comes out as its left channel, the return value counts one channel (:19, :718).
+    # KAT-12's packet (left 103, right 93) in a one-channel 16-bit stream:
+    st, pcm, out_bytes, n = oracle.decode_frame(CFG16_MONO, kat_q3_packet())
+    assert st == 0 and n == 1 and out_bytes == 2 and pcm.tolist() == [103]
+    # and two samples, uncompressed: left = [1, 32767], right = [-1, -32768] -> [1, 32767] (then the stray -32768)
+    pkt = pack([(3, 1), (4, 0), (12, 0), (1, 1), (2, 0), (1, 1), (32, 2), (16, 0x0001), (16, 0xFFFF), (16, 0x7FFF), (16, 0x8000)])
+    st, pcm, out_bytes, n = oracle.decode_frame(CFG16_MONO, pkt)
+    assert st == 0 and n == 2 and out_bytes == 4 and pcm.tolist() == [1, 32767]
