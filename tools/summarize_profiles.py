@@ -54,7 +54,7 @@ out = {
         "note": "two-pass kernel: pass 0 parks channel A's reconstructed samples in the upper half of the packet's output slot"
                 " (4 bytes per sample frame: 67 MB for cfg2) and pass 1 reads them back: writes = PCM (134 MB) + parked (67 MB),"
                 " reads = packet bytes (45 MB, cache resident across the repeated bench steps) + parked (67 MB).  That round trip"
-                " replaces the Rice-only pre-scan of channel A; at 0.87 ms per launch the 320 MB are 4.6 % of the HBM peak\n",
+                " replaces the Rice-only pre-scan of channel A\n",
     },
     "effective_clock_GHz": gui / 8 / summary["pmc_write"]["avg_kernel_ns"],
 }
@@ -66,6 +66,13 @@ json.dump({"workload": "cfg2", "kernel": kernel, "hbm_bytes_per_launch": out["tr
            "source": f"profiles/{tag}_pmc_summary.json"}, open("profiles/traffic_cfg2.json", "w"))
 shutil.copy(f"{src}/bench_default.json", f"profiles/{tag}_bench_cfg2.json")
 shutil.copy(f"{src}/cfg1_m4a.json", f"profiles/{tag}_cfg1_m4a.json")
+for extra in ("cfg2_8192", "cfg2_16384", "cfg2_32768", "two_ranks_one_gpu_gloo", "cfg3", "cfg4", "cfg5"):
+    if os.path.exists(f"{src}/{extra}.json"):
+        shutil.copy(f"{src}/{extra}.json", f"profiles/{tag}_bench_{extra}.json")
+for c in ("cfg3", "cfg4", "cfg5", "cfg2_32768"):
+    g = glob.glob(f"{src}/stats_{c}/*/*_kernel_stats.csv")
+    if g:
+        shutil.copy(max(g, key=os.path.getmtime), f"profiles/{tag}_kernel_stats_{c}.csv")
 print(open(f"profiles/{tag}_kernel_stats.csv").read().splitlines()[1])
 print("traffic", out["traffic"]["hbm_bytes_per_launch"], "clock", out["effective_clock_GHz"])
 for d in summary:
