@@ -566,6 +566,36 @@ __device__ __forceinline__ int row_suffix_scan_n(int v) {
     return v;
 }
 
+// ---- FIR fast step, 16 lanes per stream, one tap register ------------------------------------------------------
+// The steady state of fir_step for rows with 1 <= N <= 16 (i > N), branch-free: 35 instructions against the 80 of the
+// two-register step below.  Lanes >= N keep coef == 0 and w == 0.  A row that is switched off is fed err = 0 / coef = 0.
+struct FirLane {
+    int hist, coef, base;
+    int q, rnd, rss, qmask;   // row-uniform
+    uint32_t w;               // N - j for tap j < N, else 0
+    int bpaddr;               // ds_bpermute byte address of lane N-1 of this row
+    int tlo, thi;             // -1 / +1 on tap lanes (j < N), 0 / 0 elsewhere: bounds of the sign() median
+};
+__device__ __forceinline__ void fir_fast1(FirLane& f, int err) {
+    const int nb = __builtin_amdgcn_ds_bpermute(f.bpaddr, f.hist);   // tap N-1 = next step's base; needed last
+    const int d = wsub(f.hist, f.base);                                       // :303
+    const int p = wmul(d, f.coef);
+    const int sum = row_allreduce_n<4>(p);
+    const int out = __builtin_amdgcn_sbfe(wadd(wadd(wadd(f.rnd, sum) >> f.q, f.base), err), 0, f.rss);  // :306-310
+    // sign-LMS (:312-332), parallel form -- see fir_step for the derivation
+    const int s = err >> 31;
+    const int a = max(d, -d);
+    const uint32_t aq = (uint32_t)(a + (s & f.qmask)) >> f.q;
+    uint32_t cc = min(aq * f.w, 1u << 26);   // clamp: keeps the scan from wrapping, decisions unchanged
+    const uint32_t incl = (uint32_t)row_suffix_scan_n<4>((int)cc);
+    const uint32_t Ecc = (uint32_t)((err ^ s) - s) + cc;      // |err| + own decrement: visit iff |err| > incl - cc
+    int sd;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(sd) : "v"(d), "v"(f.tlo), "v"(f.thi));
+    f.coef += (Ecc > incl) ? (sd ^ s) - s : 0;
+    f.hist = __builtin_amdgcn_update_dpp(out, f.hist, DPP_ROW_SHR1, 0xF, 0xF, false);
+    f.base = nb;
+}
+
 // ---- FIR fast step, two tap registers per lane ------------------------------------------------------
 // Steady state for waves in which some stream has more than 16 taps: tap j = l + 16t in lane l, register t.
 // Rows with N <= 16 simply leave register 1 empty (coef = w = 0).  Rows with N == 31 are in the reference's

@@ -226,6 +226,10 @@ struct AbSharedT {
     uint32_t ring_next[NS];    // entropy wave -> output wave: Rice::next of the stream at the last barrier
     uint32_t ring_filled[NS];  // entropy wave -> output wave at the start of a pass: bytes staged by rice_init
     uint32_t ring_on[NS];      // stream switched on in this pass
+    // 32-tap kernel: which stream a FIR row serves in pass 0 / 1 (rows 0..3 = first FIR wave) and the inverse.  The streams
+    // of a pass are sorted by LPC order, so that the four cheapest share a wave -- which then takes the one-register step
+    // whenever their orders allow (35 instead of 80 instructions per sample step of four streams).
+    uint8_t stream_at[2][8], row_of[2][8];
 };
 typedef AbSharedT<8> AbShared;
 
@@ -578,7 +582,7 @@ __device__ __forceinline__ void ab_fir_wave2(const alac_decode_params& p, uint32
 __device__ __forceinline__ void ab_fir16_wave(const alac_decode_params& p, uint32_t pkt0, int w, int lane, AbShared& sh, int ph, int nchunks) {
     constexpr int S = 8;
     const int l = lane & 15, rowlane0 = lane & 48;
-    const int g = 4 * w + (lane >> 4);
+    const int g = sh.stream_at[ph][4 * w + (lane >> 4)];
     const uint32_t pkt = pkt0 + (uint32_t)g;
     const bool valid = pkt < p.n_packets;
     alacgpu_cfg_dev cfg;
@@ -609,6 +613,8 @@ __device__ __forceinline__ void ab_fir16_wave(const alac_decode_params& p, uint3
     const int nmax = __builtin_amdgcn_readfirstlane(wave_max(n_row));
     const int Nw = __builtin_amdgcn_readfirstlane(wave_max((stream_on && m.N != 31) ? m.N : 0));
     const bool taps_ok = __builtin_amdgcn_ballot_w64(stream_on && m.N < 1) == 0;   // fir_fast2 wants N >= 1 in every row
+    // every stream of this wave has at most 16 taps (and none is in the delta mode): one tap register does
+    const bool one_reg = Nw <= 16 && __builtin_amdgcn_ballot_w64(stream_on && m.N == 31) == 0;
     const int* qzero = &sh.zeros[0][g];
     for (int c = 0; c < nchunks; c++) {
         const int i0 = c * AB_CHUNK;
@@ -619,7 +625,21 @@ __device__ __forceinline__ void ab_fir16_wave(const alac_decode_params& p, uint3
         for (int blk = 0; blk < AB_CHUNK / 16; blk++) {
             const int ih = i0 + 16 * blk;
             if (ih < nmax) {
-                if (ih > Nw && ih > 0 && clean && taps_ok) {
+                if (ih > Nw && ih > 0 && clean && taps_ok && one_reg) {
+                    FirLane f1;
+                    f1.hist = f.hist[0]; f1.coef = f.coef[0]; f1.base = f.base;
+                    f1.q = f2.q; f1.rnd = f2.rnd; f1.rss = f2.rss; f1.qmask = f2.qmask;
+                    f1.w = f2.w[0]; f1.bpaddr = f2.bpaddr; f1.tlo = f2.tlo[0]; f1.thi = f2.thi[0];
+                    int err = q[(16 * blk) * S];
+#pragma unroll
+                    for (int ii = 0; ii < 16; ii++) {
+                        const int en = q[(16 * blk + (ii < 15 ? ii + 1 : ii)) * S];
+                        fir_fast1(f1, err);
+                        err = en;
+                    }
+                    f.hist[0] = f1.hist; f.coef[0] = f1.coef; f.base = f1.base;
+                    f.prev = __shfl(f1.hist, rowlane0, 64);     // out[i-1] = tap 0 (only the masked steps look at it)
+                } else if (ih > Nw && ih > 0 && clean && taps_ok) {
                     f2.hist[0] = f.hist[0]; f2.hist[1] = f.hist[1];
                     f2.coef[0] = f.coef[0]; f2.coef[1] = f.coef[1];
                     f2.base = f.base;
@@ -723,9 +743,10 @@ struct AbRefill {
 // Lane -> (stream g, sample j of a block of 8): P == 8 reads the FIR wave's P8 layout lane for lane; P == 16 lets lane
 // group g = lane >> 3 pick its stream's 16 outputs per block of 16 out of the two FIR waves' P16 layouts, 8 and 8.
 template <int P, int NS>
-__device__ __forceinline__ int ab_outq_read(const AbSharedT<NS>& sh, int c, int half, int w, int lane, int g, int j) {
+__device__ __forceinline__ int ab_outq_read(const AbSharedT<NS>& sh, int c, int half, int w, int lane, int g, int j, int ph) {
     if (P == 8) return sh.outq[c & 1][half][64 * w + lane];   // lane (2t + par) holds out[last - t] of its stream
-    return sh.outq[c & 1][(half & ~1) + (g >> 2)][((g & 3) << 4) + j + 8 * (half & 1)];
+    const int r = sh.row_of[ph][g];                           // the FIR row that serves stream g in this pass
+    return sh.outq[c & 1][(half & ~1) + (r >> 2)][((r & 3) << 4) + j + 8 * (half & 1)];
 }
 
 // The output work for one block of 8 streams (block w of the workgroup): what happens between two chunk barriers of pass 0
@@ -769,7 +790,7 @@ struct AbOutBlock {
             const int jb = P == 8 ? j : j + 8 * (half & 1);                                   // position in that block
             const int cnt = min(P, n_out - ih);
             if (jb >= cnt) continue;
-            const int mine = ab_outq_read<P, NS>(sh, c - 1, half, w, lane, g, j);
+            const int mine = ab_outq_read<P, NS>(sh, c - 1, half, w, lane, g, j, 0);
             if (m.esc) {                                            // uncompressed: raw samples, both channels now
                 const int i = ih + jb;
                 const int nch = m.stereo ? 2 : 1;
@@ -813,7 +834,7 @@ struct AbOutBlock {
             const int cnt = min(P, n_out - ih);
             if (!two_pass || jb >= cnt) continue;
             const int i = ih + cnt - 1 - jb;
-            const int a = a_cur[half], b = ab_outq_read<P, NS>(sh, c - 1, half, w, lane, g, j);
+            const int a = a_cur[half], b = ab_outq_read<P, NS>(sh, c - 1, half, w, lane, g, j, 1);
             int left, right;
             if (m.mixweight != 0) {                                 // AlacFile.cs:346-357 / :377-388
                 right = wsub(a, wmul(b, m.mixweight) >> (m.mixshift & 31));
@@ -883,6 +904,32 @@ __device__ __forceinline__ void ab_kernel_body(const alac_decode_params& p) {
         wide_lane = ok && !ma.esc && (ma.N > 8 || (ma.stereo && mb.N > 8));
         // the parking place needs two ints per sample in the slot (always true for a two-channel stream cfg)
         bad = bad || (n1 > 0 && (uint64_t)2 * (uint64_t)ma.n > p.slot_ints);
+    }
+    if constexpr (P == 16) {
+        // sort the streams of each pass by LPC order (see AbSharedT::stream_at): switched-off streams first (they cost nothing),
+        // then orders 1 .. 30, then the delta mode (31; two-register step only), then order 0 (masked steps: keep them together)
+        for (int ph = 0; ph < 2; ph++) {
+            // (recomputed from the headers every wave has just read; lanes 0..7 hold packet lane & 7)
+            int key;
+            {
+                const uint32_t pk = pkt0 + (uint32_t)(lane & 7);
+                const bool v = pk < p.n_packets;
+                alacgpu_cfg_dev c;
+                const Meta mm = parse_meta(p, pk, ph, v, c);
+                const bool on = v && mm.status == 0 && !mm.esc && (ph == 0 || mm.stereo);
+                key = !on ? 0 : mm.N == 31 ? 40 : mm.N == 0 ? 41 : mm.N;
+            }
+            int rank = 0;
+#pragma unroll
+            for (int j2 = 0; j2 < 8; j2++) {
+                const int kj = __shfl(key, j2, 64);
+                rank += (kj < key || (kj == key && j2 < (lane & 7))) ? 1 : 0;
+            }
+            if (wave == 0 && lane < 8) {
+                sh.stream_at[ph][rank] = (uint8_t)lane;
+                sh.row_of[ph][lane] = (uint8_t)rank;
+            }
+        }
     }
     const bool fallback = __builtin_amdgcn_ballot_w64(bad) != 0;
     // some stream (of the block of 8 a FIR wave serves) has more than 8 taps: two taps per lane
