@@ -270,38 +270,47 @@ def main():
     allgather_ms = overlapped_ms = None
     gather_ok = True
     extra = {}
-    if distributed and not args.no_allgather:
-        allgather_ms, overlapped_ms, gather_ok = measure_allgather(torch, dist, sharding, w, world, rank, dev, args.backend)
-    if distributed and not args.no_extra:
-        for cfgno in (4, 5):
-            if cfgno == args.config:
-                continue
-            npk = args.extra_packets or PER_GPU_PACKETS[cfgno]
-            we = Workload(pkg, synth, torch, np, cfgno, npk, rank, dev, local_rank)
-            ksteps = max(1, min(args.steps, 10))
-            el, kms = timed_steps(torch, dist, we, ksteps, min(args.warmup, 2), dev, True)
-            ok = we.status_ok()
-            el, kms = reduce_max(torch, dist, cdev, el, kms)
-            tot, ab, bad = reduce_sum(torch, dist, cdev, we.samples, we.algo_bytes, 0 if ok else 1)
-            row = {"workload": NAMES[cfgno], "packets_per_gpu": npk, "steps": ksteps,
-                   "value": round(tot * ksteps / el / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(el / ksteps * 1e3, 4),
-                   "kernel_ms": round(kms, 4), "roofline_frac": round(we.algo_bytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                   "status_ok": bad == 0}
-            if not args.no_allgather:
-                a_ms, o_ms, g_ok = measure_allgather(torch, dist, sharding, we, world, rank, dev, args.backend)
-                a_ms, o_ms = reduce_max(torch, dist, cdev, a_ms, o_ms)
-                row.update(allgather_ms=round(a_ms, 4), decode_allgather_overlapped_ms=round(o_ms, 4),
-                           allgather_bytes_per_rank=int(we.d_pcm.numel() * 4))
-                gather_ok = gather_ok and g_ok
-            status_ok = status_ok and bad == 0
-            extra[f"cfg{cfgno}"] = row
-            we.close()
-            del we
-    if distributed:
-        (gbad,) = reduce_sum(torch, dist, cdev, 0 if gather_ok else 1)
-        gather_ok = gbad == 0
-        if allgather_ms is not None:
-            allgather_ms, overlapped_ms = reduce_max(torch, dist, cdev, allgather_ms, overlapped_ms)
+    extra_error = None
+    # (the headline measurement above is complete at this point; a failure below -- out of memory, a collective that the
+    # node's fabric refuses -- is reported in the line as "extra_error" instead of taking `value` down with it)
+    try:
+        if distributed and not args.no_allgather:
+            allgather_ms, overlapped_ms, gather_ok = measure_allgather(torch, dist, sharding, w, world, rank, dev, args.backend)
+        if distributed and not args.no_extra:
+            for cfgno in (4, 5):
+                if cfgno == args.config:
+                    continue
+                npk = args.extra_packets or PER_GPU_PACKETS[cfgno]
+                we = Workload(pkg, synth, torch, np, cfgno, npk, rank, dev, local_rank)
+                ksteps = max(1, min(args.steps, 10))
+                el, kms = timed_steps(torch, dist, we, ksteps, min(args.warmup, 2), dev, True)
+                ok = we.status_ok()
+                el, kms = reduce_max(torch, dist, cdev, el, kms)
+                tot, ab, bad = reduce_sum(torch, dist, cdev, we.samples, we.algo_bytes, 0 if ok else 1)
+                row = {"workload": NAMES[cfgno], "packets_per_gpu": npk, "steps": ksteps,
+                       "value": round(tot * ksteps / el / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(el / ksteps * 1e3, 4),
+                       "kernel_ms": round(kms, 4), "roofline_frac": round(we.algo_bytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                       "status_ok": bad == 0}
+                if not args.no_allgather:
+                    a_ms, o_ms, g_ok = measure_allgather(torch, dist, sharding, we, world, rank, dev, args.backend)
+                    a_ms, o_ms = reduce_max(torch, dist, cdev, a_ms, o_ms)
+                    row.update(allgather_ms=round(a_ms, 4), decode_allgather_overlapped_ms=round(o_ms, 4),
+                               allgather_bytes_per_rank=int(we.d_pcm.numel() * 4))
+                    gather_ok = gather_ok and g_ok
+                status_ok = status_ok and bad == 0
+                extra[f"cfg{cfgno}"] = row
+                we.close()
+                del we
+    except Exception as e:   # noqa: BLE001
+        extra_error = f"{type(e).__name__}: {e}"[:400]
+    if distributed and extra_error is None:
+        try:
+            (gbad,) = reduce_sum(torch, dist, cdev, 0 if gather_ok else 1)
+            gather_ok = gbad == 0
+            if allgather_ms is not None:
+                allgather_ms, overlapped_ms = reduce_max(torch, dist, cdev, allgather_ms, overlapped_ms)
+        except Exception as e:   # noqa: BLE001
+            extra_error = f"{type(e).__name__}: {e}"[:400]
 
     # ---- correctness + CPU baseline (rank 0, N=1 only; the oracle is the checker, never the product) ----
     b = w.b
@@ -385,12 +394,17 @@ def main():
             line["roofline"]["traffic_note"] = traffic_note
         if extra:
             line["extra_configs"] = extra
+        if extra_error:
+            line["extra_error"] = extra_error
         if host_path:
             line["host_path"] = host_path
         print(json.dumps(line), flush=True)
     w.close()
     if distributed:
-        dist.destroy_process_group()
+        try:
+            dist.destroy_process_group()
+        except Exception:   # noqa: BLE001
+            pass
     if not status_ok or parity is False or not gather_ok:
         raise SystemExit(1)
 
