@@ -88,6 +88,10 @@ int launch(alacgpu_ctx* ctx, const alac_decode_params& p_in, hipStream_t stream)
     p.cu_arrivals = ctx->d_cu_arrivals;
     const int si = (int)(ctx->next_slot++ % N_SLOTS);
     launch_slot& sl = ctx->slots[si];
+    if (!sl.ev0) {   // slots come to life on first use (a context that makes one call at a time only ever touches... all eight, in turn)
+        HIP_TRY(ctx, hipEventCreate(&sl.ev0));
+        HIP_TRY(ctx, hipEventCreate(&sl.ev1));
+    }
     if (sl.used) HIP_TRY(ctx, hipEventSynchronize(sl.ev1));   // the pair that last used these flags has finished
     const size_t groups = ((size_t)p.n_packets + 7) / 8;
     if (groups > sl.flags_n) {
@@ -241,13 +245,9 @@ int alacgpu_create(const alacgpu_cfg* cfgs, uint32_t n_cfgs, int device, alacgpu
         std::memcpy(ctx->h_cfgs, cfgs, sizeof(alacgpu_cfg) * n_cfgs);
         if (hipMalloc((void**)&ctx->d_cfgs, sizeof(alacgpu_cfg_dev) * n_cfgs) != hipSuccess) { rc = ALACGPU_ERR_HIP; break; }
         if (hipMemcpy(ctx->d_cfgs, cfgs, sizeof(alacgpu_cfg) * n_cfgs, hipMemcpyHostToDevice) != hipSuccess) { rc = ALACGPU_ERR_HIP; break; }
-        bool ok = true;
-        for (int i = 0; i < N_HOST_STREAMS && ok; i++)
-            ok = hipStreamCreateWithFlags(&ctx->streams[i], hipStreamNonBlocking) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&ctx->ev_meta, hipEventDisableTiming) == hipSuccess;
-        for (int i = 0; i < N_SLOTS && ok; i++)
-            ok = hipEventCreate(&ctx->slots[i].ev0) == hipSuccess && hipEventCreate(&ctx->slots[i].ev1) == hipSuccess;
-        if (!ok) { rc = ALACGPU_ERR_HIP; break; }
+        // (the other streams of the host-buffer pipeline, the launch slots' events and the workspace are made on first use:
+        // a context per file -- the reference's AlacContext -- should cost next to nothing to open)
+        if (hipStreamCreateWithFlags(&ctx->streams[0], hipStreamNonBlocking) != hipSuccess) { rc = ALACGPU_ERR_HIP; break; }
         if (hipMalloc((void**)&ctx->d_cu_arrivals, 2048 * sizeof(uint32_t)) != hipSuccess ||
             hipMemset(ctx->d_cu_arrivals, 0, 2048 * sizeof(uint32_t)) != hipSuccess) { rc = ALACGPU_ERR_HIP; break; }
     } while (0);
@@ -386,7 +386,12 @@ int alacgpu_decode_batch(alacgpu_ctx* ctx, const uint8_t* blob, uint64_t blob_by
     HIP_TRY(ctx, hipMemcpyAsync(d_off, offsets, sizeof(uint64_t) * n_packets, hipMemcpyHostToDevice, s0));
     HIP_TRY(ctx, hipMemcpyAsync(d_sz, sizes, sizeof(uint32_t) * n_packets, hipMemcpyHostToDevice, s0));
     if (cfg_idx) HIP_TRY(ctx, hipMemcpyAsync(d_ci, cfg_idx, sizeof(uint16_t) * n_packets, hipMemcpyHostToDevice, s0));
-    if (nch > 1) HIP_TRY(ctx, hipEventRecord(ctx->ev_meta, s0));
+    for (int k = 1; k < nch; k++)
+        if (!ctx->streams[k]) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->streams[k], hipStreamNonBlocking));
+    if (nch > 1) {
+        if (!ctx->ev_meta) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_meta, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_meta, s0));
+    }
     for (int k = 0; k < nch; k++) {
         hipStream_t s = ctx->streams[k];
         const uint32_t cnt = lo[k + 1] - lo[k];
@@ -416,7 +421,8 @@ int alacgpu_decode_batch(alacgpu_ctx* ctx, const uint8_t* blob, uint64_t blob_by
         if (out_bytes) HIP_TRY(ctx, hipMemcpyAsync(out_bytes + lo[k], d_ob + lo[k], sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, s));
         if (out_samples) HIP_TRY(ctx, hipMemcpyAsync(out_samples + lo[k], d_os + lo[k], sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, s));
     }
-    for (int k = 0; k < nch; k++) HIP_TRY(ctx, hipStreamSynchronize(ctx->streams[k]));
+    for (int k = 0; k < nch; k++)
+        if (ctx->streams[k]) HIP_TRY(ctx, hipStreamSynchronize(ctx->streams[k]));
     return ALACGPU_OK;
 }
 
