@@ -612,20 +612,28 @@ struct FirLane2 {
     bool delta;    // N == 31
 };
 
+// DELTA: some row of the wave is in the delta mode (else the three instructions of that select are left out).
+template <bool DELTA>
 __device__ __forceinline__ void fir_fast2(FirLane2& f, int err) {
     const int nb = __builtin_amdgcn_ds_bpermute(f.bpaddr, f.bphi ? f.hist[1] : f.hist[0]);
     const int d0 = wsub(f.hist[0], f.base), d1 = wsub(f.hist[1], f.base);
     const int p = wadd(wmul(d0, f.coef[0]), wmul(d1, f.coef[1]));
     const int sum = row_allreduce_n<4>(p);
     const int outg = __builtin_amdgcn_sbfe(wadd(wadd(wadd(f.rnd, sum) >> f.q, f.base), err), 0, f.rss);
-    const int outd = __builtin_amdgcn_sbfe(wadd(f.prev, err), 0, f.rss);
-    const int out = f.delta ? outd : outg;
+    int out = outg;
+    if (DELTA) {
+        const int outd = __builtin_amdgcn_sbfe(wadd(f.prev, err), 0, f.rss);
+        out = f.delta ? outd : outg;
+    }
     const int s = err >> 31;
     const int rq = s & f.qmask;
     const int a0 = max(d0, -d0), a1 = max(d1, -d1);
     const uint32_t q0 = (uint32_t)(a0 + rq) >> f.q, q1 = (uint32_t)(a1 + rq) >> f.q;
     const uint32_t c0 = min(q0 * f.w[0], 1u << 26), c1 = min(q1 * f.w[1], 1u << 26);   // clamp: see fir_step
     const uint32_t i1 = (uint32_t)row_suffix_scan_n<4>((int)c1);
+    // (register 1's total is also i1 in lane 0 of the row; fetching it with one ds_bpermute instead of this second
+    // reduction saves three issue slots -- cfg5 at 16384 packets -4.5 % -- but puts the cross-lane latency on the
+    // coefficient chain: +2 % at 4096 packets, where this step's chain sets the time.  Measured; not taken.)
     const uint32_t t1 = (uint32_t)row_allreduce_n<4>((int)c1);
     const uint32_t i0 = (uint32_t)row_suffix_scan_n<4>((int)c0) + t1;
     const uint32_t E = (uint32_t)((err ^ s) - s);
@@ -638,7 +646,7 @@ __device__ __forceinline__ void fir_fast2(FirLane2& f, int err) {
     f.hist[1] = __builtin_amdgcn_update_dpp(carry, f.hist[1], DPP_ROW_SHR1, 0xF, 0xF, false);
     f.hist[0] = __builtin_amdgcn_update_dpp(out, f.hist[0], DPP_ROW_SHR1, 0xF, 0xF, false);
     f.base = nb;
-    f.prev = out;
+    if (DELTA) f.prev = out;
 }
 
 // ---- "P8" layout: 8 lanes per stream, the two channels of a packet interleaved in one row -----------------

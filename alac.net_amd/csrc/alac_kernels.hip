@@ -614,7 +614,8 @@ __device__ __forceinline__ void ab_fir16_wave(const alac_decode_params& p, uint3
     const int Nw = __builtin_amdgcn_readfirstlane(wave_max((stream_on && m.N != 31) ? m.N : 0));
     const bool taps_ok = __builtin_amdgcn_ballot_w64(stream_on && m.N < 1) == 0;   // fir_fast2 wants N >= 1 in every row
     // every stream of this wave has at most 16 taps (and none is in the delta mode): one tap register does
-    const bool one_reg = Nw <= 16 && __builtin_amdgcn_ballot_w64(stream_on && m.N == 31) == 0;
+    const bool any_delta = __builtin_amdgcn_ballot_w64(stream_on && m.N == 31) != 0;
+    const bool one_reg = Nw <= 16 && !any_delta;
     const int* qzero = &sh.zeros[0][g];
     for (int c = 0; c < nchunks; c++) {
         const int i0 = c * AB_CHUNK;
@@ -645,11 +646,21 @@ __device__ __forceinline__ void ab_fir16_wave(const alac_decode_params& p, uint3
                     f2.base = f.base;
                     f2.prev = f.prev;
                     int err = q[(16 * blk) * S];
+                    if (__builtin_expect(!any_delta, 1)) {
 #pragma unroll
-                    for (int ii = 0; ii < 16; ii++) {
-                        const int en = q[(16 * blk + (ii < 15 ? ii + 1 : ii)) * S];
-                        fir_fast2(f2, err);
-                        err = en;
+                        for (int ii = 0; ii < 16; ii++) {
+                            const int en = q[(16 * blk + (ii < 15 ? ii + 1 : ii)) * S];
+                            fir_fast2<false>(f2, err);
+                            err = en;
+                        }
+                        f2.prev = __shfl(f2.hist[0], rowlane0, 64);   // out[i-1] = tap 0 (only the masked steps look at it)
+                    } else {
+#pragma unroll
+                        for (int ii = 0; ii < 16; ii++) {
+                            const int en = q[(16 * blk + (ii < 15 ? ii + 1 : ii)) * S];
+                            fir_fast2<true>(f2, err);
+                            err = en;
+                        }
                     }
                     f.hist[0] = f2.hist[0]; f.hist[1] = f2.hist[1];
                     f.coef[0] = f2.coef[0]; f.coef[1] = f2.coef[1];
