@@ -45,6 +45,8 @@ def main():
         orders = [np.arange(0, 32), np.arange(1, 9), np.array([8]), np.arange(9, 17), np.arange(17, 32)][int(rng.integers(0, 5))]
         count = int(rng.integers(1, 97))
         d = recipes(rng, count, stereo, is24, orders)
+        if stereo and rng.random() < 0.3:
+            d["stereo"] = rng.integers(0, 2, count)     # one-channel elements inside a two-channel stream: L = sample, R = 0
         sig = synth.default_signal(int(rng.integers(0, 1 << 31)))
         sig["silence_prob"] = float(rng.choice([0.0, 0.3, 1.0]))
         sig["silence_min"], sig["silence_max"] = 1, int(rng.choice([40, 3000]))
@@ -58,6 +60,8 @@ def main():
             skipped += 1
             continue
         cfgs = [(4096, 24 if is24 else 16, 40, 10, 14, 2 if stereo else 1)]
+        nc = 2 if stereo else 1
+        b["slot_ints"] = int(d["n"].max()) * nc          # (one-channel elements in a two-channel stream still fill two channels)
         o = orc.decode_batch(orc.make_cfgs(cfgs), b["blob"], b["offsets"], b["sizes"], None, b["slot_ints"], n_threads=8)
         assert (o[3] == 0).all(), o[3]
         for variant in ("8-packet", "dense"):   # both arrangements of the main kernel (ALACGPU_DENSE is read at create time)
@@ -66,11 +70,22 @@ def main():
                 g = ctx.decode_batch(b["blob"], b["offsets"], b["sizes"], None, b["slot_ints"])
                 assert np.array_equal(g[3], o[3]) and np.array_equal(g[1], o[1]) and np.array_equal(g[2], o[2]), (rounds, variant)
                 for p in range(count):
-                    cnt = int(d["n"][p]) * (2 if stereo else 1)
+                    cnt = int(d["n"][p]) * nc
                     if not np.array_equal(g[0][p, :cnt], o[0][p, :cnt]):
                         bad = np.nonzero(g[0][p, :cnt] != o[0][p, :cnt])[0]
                         raise SystemExit(f"MISMATCH round {rounds} seed {seed} variant {variant} packet {p} order {d['pred_order'][p]} "
                                          f"n {d['n'][p]} first bad index {bad[:5]}")
+                if rounds % 4 == 0:      # the packed little-endian format (FormatSamples fused into the store)
+                    ctx.set_output_format(1)
+                    gp = ctx.decode_batch(b["blob"], b["offsets"], b["sizes"], None, b["slot_ints"])
+                    bps = 3 if is24 else 2
+                    for p in range(count):
+                        cnt = int(d["n"][p]) * nc
+                        v = o[0][p, :cnt].astype(np.int64)
+                        exp = np.stack([(v >> (8 * k)) & 0xFF for k in range(bps)], axis=1).astype(np.uint8).reshape(-1)
+                        got = gp[0][p].view(np.uint8)[: cnt * bps]
+                        if not np.array_equal(got, exp):
+                            raise SystemExit(f"PACKED MISMATCH round {rounds} seed {seed} variant {variant} packet {p}")
         rounds += 1
         packets += count
         if time.time() - last_note > 30:    # a long run has to show signs of life (gpurun kills silent commands)
