@@ -45,6 +45,8 @@ SYMBOLS = {
     "alacgpu_destroy": (None, [_VP]),
     "alacgpu_cfg_from_codec_data": (C.c_int, [_VP, C.c_uint32, C.c_int, C.c_int, _VP]),
     "alacgpu_decode_batch": (C.c_int, [_VP, _VP, C.c_uint64, _VP, _VP, _VP, C.c_uint32, _VP, C.c_uint32, _VP, _VP, _VP]),
+    "alacgpu_decode_batch_sharded": (C.c_int, [_VP, C.c_uint32, _VP, C.c_uint64, _VP, _VP, _VP, C.c_uint32, _VP, C.c_uint32, _VP,
+                                               _VP, _VP]),
     "alacgpu_decode_batch_device": (C.c_int, [_VP, _VP, C.c_uint64, _VP, _VP, _VP, C.c_uint32, _VP, C.c_uint32, _VP,
                                               _VP, _VP, _VP]),
     "alacgpu_decode_frame": (C.c_int, [_VP, C.c_uint32, _VP, C.c_uint32, _VP, C.c_uint32, _VP, _VP]),
@@ -199,6 +201,29 @@ class AlacGpuContext:
                                         C.byref(st))
         _check(rc, self._ctx)
         return out, ob.value, st.value
+
+
+def decode_batch_sharded(contexts, blob, offsets, sizes, cfg_idx=None, slot_ints=None, out=None):
+    """alacgpu_decode_batch_sharded: one host batch over several AlacGpuContext objects (one per GPU) from this process.
+    Returns (pcm[n, slot_ints] int32, out_bytes[n], out_samples[n], status[n]) like AlacGpuContext.decode_batch."""
+    blob = np.ascontiguousarray(blob, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    sizes = np.ascontiguousarray(sizes, dtype=np.uint32)
+    ci = None if cfg_idx is None else np.ascontiguousarray(cfg_idx, dtype=np.uint16)
+    n = len(sizes)
+    if slot_ints is None:
+        slot_ints = int(max(int(c["max_samples_per_frame"]) * int(c["num_channels"]) for c in contexts[0].cfgs))
+    pcm = out if out is not None else np.zeros((n, slot_ints), dtype=np.int32)
+    if pcm.dtype != np.int32 or pcm.shape != (n, slot_ints) or not pcm.flags.c_contiguous:
+        raise ValueError("out must be a C-contiguous int32 array of shape (n_packets, slot_ints)")
+    ob = np.zeros(n, dtype=np.int32)
+    os_ = np.zeros(n, dtype=np.int32)
+    st = np.zeros(n, dtype=np.int32)
+    handles = (_VP * len(contexts))(*[c._ctx for c in contexts])
+    rc = lib().alacgpu_decode_batch_sharded(handles, len(contexts), _ptr(blob), blob.size, _ptr(offsets), _ptr(sizes), _ptr(ci), n,
+                                            _ptr(pcm), slot_ints, _ptr(ob), _ptr(os_), _ptr(st))
+    _check(rc, contexts[0]._ctx)
+    return pcm, ob, os_, st
 
 
 class PinnedBuffer:

@@ -8,6 +8,8 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "alac_kernels.h"
 #include "alacgpu.h"
@@ -423,6 +425,43 @@ int alacgpu_decode_batch(alacgpu_ctx* ctx, const uint8_t* blob, uint64_t blob_by
     }
     for (int k = 0; k < nch; k++)
         if (ctx->streams[k]) HIP_TRY(ctx, hipStreamSynchronize(ctx->streams[k]));
+    return ALACGPU_OK;
+}
+
+// One batch on HOST buffers over several contexts -- normally one per GPU of the node -- from one process: contiguous packet
+// ranges (whole groups of 8), one host thread per context, every range through alacgpu_decode_batch of its context.  The
+// ranges write disjoint parts of the caller's arrays, so there is nothing to gather.
+int alacgpu_decode_batch_sharded(alacgpu_ctx* const* ctxs, uint32_t n_ctxs, const uint8_t* blob, uint64_t blob_bytes,
+                                 const uint64_t* offsets, const uint32_t* sizes, const uint16_t* cfg_idx, uint32_t n_packets,
+                                 int32_t* pcm_out, uint32_t slot_ints, int32_t* out_bytes, int32_t* out_samples, int32_t* status) {
+    if (!ctxs || n_ctxs == 0) return ALACGPU_ERR_BAD_ARG;
+    for (uint32_t r = 0; r < n_ctxs; r++)
+        if (!ctxs[r] || ctxs[r]->n_cfgs != ctxs[0]->n_cfgs || ctxs[r]->out_format != ctxs[0]->out_format) return ALACGPU_ERR_BAD_ARG;
+    if (n_packets == 0) return ALACGPU_OK;
+    if (!blob || !offsets || !sizes || !pcm_out || !status || slot_ints == 0) return ALACGPU_ERR_BAD_ARG;
+    if (n_ctxs == 1)
+        return alacgpu_decode_batch(ctxs[0], blob, blob_bytes, offsets, sizes, cfg_idx, n_packets, pcm_out, slot_ints, out_bytes,
+                                    out_samples, status);
+    std::vector<uint32_t> lo(n_ctxs + 1);
+    for (uint32_t r = 0; r <= n_ctxs; r++)
+        lo[r] = std::min<uint64_t>(n_packets, (((uint64_t)n_packets * r / n_ctxs) + 7u) & ~7ull);
+    lo[0] = 0;
+    lo[n_ctxs] = n_packets;
+    std::vector<int> rcs(n_ctxs, ALACGPU_OK);
+    std::vector<std::thread> workers;
+    workers.reserve(n_ctxs);
+    for (uint32_t r = 0; r < n_ctxs; r++) {
+        const uint32_t a = lo[r], cnt = lo[r + 1] - lo[r];
+        if (cnt == 0) continue;
+        workers.emplace_back([=, &rcs]() {
+            rcs[r] = alacgpu_decode_batch(ctxs[r], blob, blob_bytes, offsets + a, sizes + a, cfg_idx ? cfg_idx + a : nullptr, cnt,
+                                          pcm_out + (size_t)a * slot_ints, slot_ints, out_bytes ? out_bytes + a : nullptr,
+                                          out_samples ? out_samples + a : nullptr, status + a);
+        });
+    }
+    for (auto& t : workers) t.join();
+    for (uint32_t r = 0; r < n_ctxs; r++)
+        if (rcs[r] != ALACGPU_OK) return rcs[r];
     return ALACGPU_OK;
 }
 

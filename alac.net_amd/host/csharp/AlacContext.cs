@@ -42,6 +42,25 @@ namespace ALACdotNET.Decoder
             _alac = new AlacFile(_demuxRes.SampleSize, _demuxRes.NumChannels);
             _alac.SetInfo(_demuxRes.CodecData);
             AlacFile.Check(AlacGpuNative.alacgpu_set_output_format(_alac.Context, AlacGpuNative.OutPackedLe));
+            _contexts = new[] { _alac.Context };
+        }
+
+        /// <summary>New: spread every ReadBatch over the first `gpus` GPUs of the node (alacgpu_device_count tells how many there
+        /// are): one more context per extra device, and alacgpu_decode_batch_sharded cuts each batch into contiguous packet
+        /// ranges, one native thread per GPU.  Worth it for batches of several thousand packets per GPU.</summary>
+        public void UseGpus(int gpus)
+        {
+            int n = Math.Max(1, Math.Min(gpus, AlacGpuNative.alacgpu_device_count()));
+            var list = new IntPtr[n];
+            list[0] = _alac.Context;
+            var cfg = new[] { _alac.Config };
+            for (int d = 1; d < n; d++)
+            {
+                AlacFile.Check(AlacGpuNative.alacgpu_create(cfg, 1, d, out list[d]));
+                AlacFile.Check(AlacGpuNative.alacgpu_set_output_format(list[d], AlacGpuNative.OutPackedLe));
+            }
+            for (int d = 1; d < _contexts.Length; d++) AlacGpuNative.alacgpu_destroy(_contexts[d]);
+            _contexts = list;
         }
 
         private readonly DemuxResT _demuxRes;
@@ -52,6 +71,7 @@ namespace ALACdotNET.Decoder
         private bool _disposed;
         private int _currentSampleBlock;     // next packet to FETCH (the decoded queue may hold earlier ones)
         private int _offset;                 // post-seek offset, in ints of the reference's decode buffer
+        private IntPtr[] _contexts;          // [0] = _alac's; more after UseGpus
 
         // ---- the decoded batch: packed little-endian PCM, slot p at p * SlotBytes ----
         private byte[] _blob = new byte[0];
@@ -139,8 +159,8 @@ namespace ALACdotNET.Decoder
             {
                 long need = (long)count * _slotInts;
                 if (_pcm.Length < need) _pcm = new int[need];
-                AlacFile.Check(AlacGpuNative.alacgpu_decode_batch(_alac.Context, _blob, (ulong)total, _offsets, _sizes, null, (uint)count,
-                                                                  _pcm, _slotInts, _outBytes, _outSamples, _status));
+                AlacFile.Check(AlacGpuNative.alacgpu_decode_batch_sharded(_contexts, (uint)_contexts.Length, _blob, (ulong)total, _offsets, _sizes,
+                                                                          null, (uint)count, _pcm, _slotInts, _outBytes, _outSamples, _status));
                 bool tooSmall = false;
                 for (int p = 0; p < count; p++) tooSmall |= _status[p] == AlacGpuNative.StBadSampleCount;
                 if (!tooSmall || _slotInts >= 16384u * channels) break;
@@ -236,6 +256,8 @@ namespace ALACdotNET.Decoder
         private void ReleaseAll(bool disposing)
         {
             if (_disposed) return;
+            if (_contexts != null)
+                for (int d = 1; d < _contexts.Length; d++) AlacGpuNative.alacgpu_destroy(_contexts[d]);
             _alac?.Dispose();
             if (disposing && _disposeStream) _inputStream?.Dispose();
             _disposed = true;

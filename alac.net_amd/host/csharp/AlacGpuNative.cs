@@ -36,6 +36,11 @@ namespace ALACdotNET.Decoder
         [DllImport(Lib)] public static extern int alacgpu_decode_batch(IntPtr ctx, [In] byte[] blob, ulong blobBytes,
             [In] ulong[] offsets, [In] uint[] sizes, [In] ushort[] cfgIdx, uint nPackets,
             [Out] int[] pcmOut, uint slotInts, [Out] int[] outBytes, [Out] int[] outSamples, [Out] int[] status);
+        /// <summary>One batch over several contexts (one per GPU, alacgpu_device_count) from this process: contiguous packet
+        /// ranges, one native thread per context, every range writes its own part of the arrays.</summary>
+        [DllImport(Lib)] public static extern int alacgpu_decode_batch_sharded([In] IntPtr[] ctxs, uint nCtxs, [In] byte[] blob, ulong blobBytes,
+            [In] ulong[] offsets, [In] uint[] sizes, [In] ushort[] cfgIdx, uint nPackets,
+            [Out] int[] pcmOut, uint slotInts, [Out] int[] outBytes, [Out] int[] outSamples, [Out] int[] status);
         // the same entry point over raw pointers (pinned / alacgpu_alloc_pinned memory; packed output viewed as bytes)
         [DllImport(Lib, EntryPoint = "alacgpu_decode_batch")] public static extern int alacgpu_decode_batch_ptr(IntPtr ctx, IntPtr blob, ulong blobBytes,
             [In] ulong[] offsets, [In] uint[] sizes, [In] ushort[] cfgIdx, uint nPackets,

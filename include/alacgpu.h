@@ -105,6 +105,19 @@ int alacgpu_decode_batch(alacgpu_ctx* ctx, const uint8_t* blob, uint64_t blob_by
                          uint32_t slot_ints, int32_t* out_bytes, int32_t* out_samples, int32_t* status);
 
 /*
+ * The same batch over SEVERAL contexts from one process -- normally one context per GPU of the node (alacgpu_device_count,
+ * alacgpu_create with device = 0, 1, ...): the packets are cut into n_ctxs contiguous ranges, one host thread per
+ * context runs alacgpu_decode_batch on its range, and every range writes its own part of the caller's arrays (nothing
+ * to gather).  All contexts must have been created with the same cfgs and output format.  This is how a single-process
+ * host (the C# AlacContext) uses every GPU of a node; the multi-process form (one rank per GPU, RCCL all-gather of the
+ * PCM) is what bench.py and alac.net_amd/sharding.py do.
+ */
+int alacgpu_decode_batch_sharded(alacgpu_ctx* const* ctxs, uint32_t n_ctxs, const uint8_t* blob, uint64_t blob_bytes,
+                                 const uint64_t* offsets, const uint32_t* sizes, const uint16_t* cfg_idx, uint32_t n_packets,
+                                 int32_t* pcm_out, uint32_t slot_ints, int32_t* out_bytes, int32_t* out_samples,
+                                 int32_t* status);
+
+/*
  * Same, on DEVICE buffers already resident in HBM (all pointers are device pointers), asynchronous on
  * `hip_stream` (a hipStream_t; NULL = default stream).  d_blob must be 16-byte aligned and readable up to
  * blob_bytes rounded up to 16 (ALACGPU_ERR_BAD_ARG otherwise; the other arrays need their natural alignment).

@@ -164,3 +164,26 @@ def test_pinned_buffers_and_chunked_host_path(pkg, oracle, synth):
         pcm, ob, os_, st = ctx.decode_batch(b["blob"], b["offsets"][perm], b["sizes"][perm],
                                             None if b["cfg_idx"] is None else b["cfg_idx"][perm], b["slot_ints"])
         assert np.array_equal(st, ref[3][perm]) and _same_pcm(b, pcm, ref, perm)
+
+
+def test_one_batch_over_several_contexts_from_one_process(pkg, oracle, synth):
+    # alacgpu_decode_batch_sharded: how a single-process host uses every GPU of a node (one context per device, one native
+    # thread each).  One GPU here, so three contexts on the same device; uneven ranges and a batch smaller than the
+    # number of contexts included
+    b = synth.make_config_batch(5, n_packets=1501)
+    ref = _oracle(oracle, b)
+    ctxs = [pkg.AlacGpuContext(b["stream_cfgs"], device=0) for _ in range(3)]
+    try:
+        pcm, ob, os_, st = pkg.decode_batch_sharded(ctxs, b["blob"], b["offsets"], b["sizes"], b["cfg_idx"], b["slot_ints"])
+        assert np.array_equal(st, ref[3]) and np.array_equal(ob, ref[1]) and np.array_equal(os_, ref[2])
+        assert _same_pcm(b, pcm, ref)
+        b2 = synth.make_config_batch(2, n_packets=2)
+        ctx2 = [pkg.AlacGpuContext(b2["stream_cfgs"], device=0) for _ in range(3)]
+        r2 = _oracle(oracle, b2)
+        g2 = pkg.decode_batch_sharded(ctx2, b2["blob"], b2["offsets"], b2["sizes"], None, b2["slot_ints"])
+        assert (g2[3] == 0).all() and np.array_equal(g2[0], r2[0])
+        for c in ctx2:
+            c.close()
+    finally:
+        for c in ctxs:
+            c.close()
