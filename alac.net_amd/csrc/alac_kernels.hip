@@ -6,7 +6,7 @@
 // :256-336 = predictor_decompress_fir_adapt) and mid/side un-mixing + store (Deinterlace16/24
 // :338-421), integer only, bit-exact with the reference's C# int semantics.
 //
-// One kernel family lives here, the "two-pass" kernels: 8 packets per workgroup, channel A decoded
+// One kernel family lives here, the "two-pass" kernels: 8 (or 16) packets per workgroup, channel A decoded
 // for real in pass 0 (its end is where B starts: no Rice-only pre-scan), parked in the packet's own output slot, and
 // un-mixed with B in pass 1; one-channel and uncompressed packets finish in pass 0.  Per workgroup: an entropy wave
 // (bitstream staged in per-stream LDS rings, branch-free speculative Rice units -> LDS residual queue), one or two FIR
@@ -212,7 +212,7 @@ __device__ __forceinline__ int mirror_i(int v, int src) { return __shfl(v, src, 
 #ifndef ALAC_AB_CHUNK
 #define ALAC_AB_CHUNK 32
 #endif
-constexpr int AB_CHUNK = ALAC_AB_CHUNK;   // samples per barrier: twice the split kernels' (half the per-chunk overhead of the critical wave)
+constexpr int AB_CHUNK = ALAC_AB_CHUNK;   // samples per barrier (16 were measured too: the critical wave pays its per-chunk overhead twice as often)
 // NS = streams (packets) per workgroup: 8 (one entropy wave of 8 lanes per stream, one FIR wave, one output wave) or 16 (the
 // "dense" arrangement for big batches: ONE entropy wave serves 16 streams with 4 lanes each -- its instructions, more than half
 // of all the kernel issues, are shared by twice as many packets -- next to two FIR waves and two output waves of 8 streams).
@@ -442,7 +442,8 @@ __device__ __forceinline__ void ab_entropy_wave(const alac_decode_params& p, uin
     }
 }
 
-// FIR wave: the P8 layout of recon8_wave with the 8 rows' two parities holding the SAME channel of 8 different packets.
+// FIR wave, P8 layout (alac_device.h: fir8_step): 8 lanes per stream, the two parities of a row of 16 lanes hold the SAME
+// channel of two different packets, so one wave serves the 8 streams of a pass.
 // w: which block of 8 streams of the workgroup this wave serves (always 0 when NS == 8).
 template <int NS>
 __device__ __forceinline__ void ab_fir_wave(const alac_decode_params& p, uint32_t pkt0, int w, int lane, AbSharedT<NS>& sh, int ph, int nchunks) {
@@ -576,7 +577,7 @@ __device__ __forceinline__ void ab_fir_wave2(const alac_decode_params& p, uint32
     wg_sync();  // final barrier of the pass
 }
 
-// FIR wave of the 32-tap variant (alac_decode_ab32_kernel): the P16 layout of recon_wave_impl with two tap registers per
+// FIR wave of the 32-tap variant (alac_decode_ab32_kernel): the P16 layout (a row of 16 lanes per stream) with two tap registers per
 // lane (tap j = l + 16 t of a stream in lane l of its row of 16; fir_fast2, which also does the delta mode N == 31), four
 // packets per wave, two such waves per workgroup (w = 0 / 1: packets 0..3 / 4..7).  The queue carries residuals here.
 __device__ __forceinline__ void ab_fir16_wave(const alac_decode_params& p, uint32_t pkt0, int w, int lane, AbShared& sh, int ph, int nchunks) {
@@ -896,7 +897,7 @@ __device__ __forceinline__ void ab_kernel_body(const alac_decode_params& p) {
     __shared__ __attribute__((aligned(1024))) AbSharedT<NS> sh;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t pkt0 = blockIdx.x * (uint32_t)NS;
-    // ab_flags[group]: 0 = decoded by alac_decode_ab_kernel, 2 = by alac_decode_ab32_kernel, 1 = left to the split kernel
+    // ab_flags[group]: 0 = decoded by alac_decode_ab_kernel, 1 = left for alac_decode_ab32_kernel, 2 = decoded by it
     if (P == 16 && (!p.ab_flags || p.ab_flags[blockIdx.x] == 0u)) return;
     // every wave reads all 8 headers: pass lengths (uniform over the workgroup) and whether the P8 layout fits
     int n0 = 0, n1 = 0;
@@ -1039,9 +1040,6 @@ __device__ __forceinline__ void ab_kernel_body(const alac_decode_params& p) {
 
 }  // namespace
 
-// The 4- and 8-wave-per-workgroup kernels serve big batches, where exactly-full occupancy is a cliff (a
-// workgroup that does not fit waits for a whole round): cap them at 80 VGPRs = 6 waves per SIMD.  The small-batch
-// kernels never fill the CU and keep the unconstrained allocation.
 // 96 registers for the main kernel: five workgroups per CU instead of four once a batch has more than fit at once
 // (cfg2 at 16384 packets 2.38 -> 2.00 ms, 32768 4.10 -> 3.68; the 44 bytes of scratch are in rarely executed parts, and
 // the small batches did not lose: 4096 packets 0.814 -> 0.804 ms).
