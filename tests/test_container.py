@@ -160,11 +160,16 @@ def test_cpp_alaccontext_mirror(synth, tmp_path, sample_size):
     total = int(d["n"].sum())
     assert out.stdout.strip() == (f"rate=44100 channels=2 bits={sample_size} samples={total} bytes={len(exp)} "
                                   f"fnv={_fnv(exp)} last={total}"), out.stdout
+    pos = 4096 * 5 + 321
+    out = subprocess.run([exe, str(path), str(pos)], capture_output=True, text=True, timeout=120)
     if sample_size == 16:
-        pos = 4096 * 5 + 321
-        out = subprocess.run([exe, str(path), str(pos)], capture_output=True, text=True, timeout=120)
         exp = pcm[pos * 2: 6 * 4096 * 2].astype("<i2").tobytes()
-        assert out.stdout.strip() == f"seek bytes={len(exp)} fnv={_fnv(exp)} last={7 * 4096}", out.stdout
+    else:
+        # the 24-bit seek quirk (see test_alaccontext_seek_24bit_quirk): starts _offset BYTES into the frame
+        fb, off = 4096 * 2 * 3, 321 * 2
+        packed = b"".join(int(v).to_bytes(4, "little", signed=True)[:3] for v in pcm[5 * 4096 * 2: 6 * 4096 * 2])
+        exp = packed[off: off + fb - 3 * off]
+    assert out.stdout.strip() == f"seek bytes={len(exp)} fnv={_fnv(exp)} last={7 * 4096}", out.stdout
     # the reference rejects mdat-before-moov files (QTMovieT.cs:746): same exception text as AlacContext.cs:50
     bad, *_ = make_file(synth, n_packets=2, mdat_first=True)
     p2 = tmp_path / "bad.m4a"
