@@ -51,6 +51,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-extra", action="store_true", help="N>1: skip the cfg4 / cfg5 extra measurements")
     ap.add_argument("--extra-packets", type=int, default=None, help="packets per GPU of the extra configs (rehearsals)")
     ap.add_argument("--no-host-path", action="store_true", help="N=1: skip the PCIe-inclusive and latency measurements")
+    ap.add_argument("--no-big-batch", action="store_true", help="N=1: skip the extra line for a 32768-packet batch of the same config")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 path)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     return ap.parse_args(argv)
@@ -352,6 +353,21 @@ def main():
         }
     if rank == 0 and world == 1 and not args.no_host_path:
         host_path = measure_host_path(pkg, np, w)
+    # ---- the same config in a batch big enough to fill the chip (never `value`: BASELINE quotes the metric on 4096 packets) ----
+    big_batch = None
+    if rank == 0 and world == 1 and not args.no_big_batch and args.packets is None and args.config == 2:
+        try:
+            wb = Workload(pkg, synth, torch, np, args.config, 32768, 0, dev, local_rank)
+            el, kms = timed_steps(torch, dist, wb, 5, 2, dev, False)
+            big_batch = {"packets": 32768, "steps": 5, "value": round(wb.samples * 5 / el / 1e6, 3), "unit": "Msamples/s",
+                         "kernel": "alac_decode_ab_dense_kernel", "kernel_ms": round(kms, 4),
+                         "roofline_frac": round(wb.algo_bytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "status_ok": wb.status_ok(),
+                         "note": "the main kernel's 16-packets-per-workgroup arrangement (batches above 12288 packets); "
+                                 "bound by VALU issue, not by one packet's serial chain"}
+            wb.close()
+            del wb
+        except Exception as e:   # noqa: BLE001
+            big_batch = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     if rank == 0:
         kernel_name = "alac_decode_ab_kernel"
@@ -398,6 +414,8 @@ def main():
             line["extra_error"] = extra_error
         if host_path:
             line["host_path"] = host_path
+        if big_batch:
+            line["big_batch"] = big_batch
         print(json.dumps(line), flush=True)
     w.close()
     if distributed:

@@ -43,7 +43,7 @@ def test_two_ranks_started_by_bench_itself_product_path():
 
 @pytest.mark.gpu
 def test_single_gpu_line_has_the_contract_keys_and_parity():
-    r, j = _run(["--packets", "512", "--steps", "3", "--warmup", "1", "--cpu-seconds", "0.5"])
+    r, j = _run(["--packets", "512", "--steps", "3", "--warmup", "1", "--cpu-seconds", "0.5", "--no-big-batch"])
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
