@@ -93,6 +93,14 @@ def _free_port():
 def spawn_ranks(args, argv):
     ndev = _visible_gpu_count()
     if not args.same_device and ndev is not None and ndev < args.gpus:
+        # sysfs says too few: ask the runtime itself, in a child (this process stays away from the GPU)
+        try:
+            r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True,
+                               text=True, timeout=300)
+            ndev = max(ndev, int(r.stdout.strip().splitlines()[-1]))
+        except Exception:   # noqa: BLE001
+            pass
+    if not args.same_device and ndev is not None and ndev < args.gpus:
         print(json.dumps({"error": f"--gpus {args.gpus} asked for, {ndev} GPU(s) visible", "n_gpus": args.gpus}), flush=True)
         return 2
     env = dict(os.environ)
