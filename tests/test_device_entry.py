@@ -187,3 +187,23 @@ def test_one_batch_over_several_contexts_from_one_process(pkg, oracle, synth):
     finally:
         for c in ctxs:
             c.close()
+
+
+def test_packed_output_through_the_two_range_host_path(pkg, oracle, synth):
+    # ALACGPU_OUT_PACKED_LE (FormatSamples fused into the store) on a batch big enough to be cut into two ranges: each range
+    # downloads the packed part of its slots with a strided copy; mixed 16 / 24-bit stream cfgs
+    b = synth.make_config_batch(5, n_packets=1300)
+    ref = _oracle(oracle, b)
+    with pkg.AlacGpuContext(b["stream_cfgs"]) as ctx:
+        ctx.set_output_format(1)
+        pcm, ob, os_, st = ctx.decode_batch(b["blob"], b["offsets"], b["sizes"], b["cfg_idx"], b["slot_ints"])
+    assert np.array_equal(st, ref[3]) and np.array_equal(ob, ref[1])
+    for p in range(1300):
+        if ref[3][p] != 0:
+            continue
+        cfg = b["stream_cfgs"][int(b["cfg_idx"][p])]
+        bps, cnt = cfg[1] // 8, int(ref[2][p]) * cfg[5]
+        v = ref[0][p, :cnt].astype(np.int64)
+        exp = np.stack([(v >> (8 * k)) & 0xFF for k in range(bps)], axis=1).astype(np.uint8).reshape(-1)
+        assert np.array_equal(pcm[p].view(np.uint8)[: cnt * bps], exp), p
+        assert int(ob[p]) == cnt * bps
