@@ -98,6 +98,12 @@ __device__ __forceinline__ void spec_unpark(Rice& rs, const Rice& snap, bool par
 struct SpecStats {
 #ifdef ALAC_DIAG
     int plain_ok = 0, fail_esc = 0, fail_run = 0, z_units = 0, esc_units = 0, full_units = 0, late_run = 0, redo = 0;
+    // cycle accounts of the entropy wave (s_memtime around the parts; the stamps themselves cost ~100 cycles per unit):
+    long long plain_cycles = 0;   // inside the 8 steps of plain-tier units
+    long long bar_cycles = 0;     // waiting at the chunk barriers
+    long long setup = 0;          // pass entry -> first chunk (header facts, ring fill)
+    long long slow_chunk = 0;     // chunks decoded by the generic step
+    long long t_pass = 0;
 #endif
 };
 #ifdef ALAC_DIAG
@@ -118,11 +124,17 @@ __device__ __forceinline__ bool spec_unit(Rice& rs, int& full_left, const RiceCf
     int hmin = 0x7FFFFFFF;
     if (full_left == 0) {
         if (!special) {
+#ifdef ALAC_DIAG
+            const long long tA = clock64();
+#endif
 #pragma unroll
             for (int ii = 0; ii < SPEC_UNIT; ii++) {
                 const int r = rice_spec_step<WANT_R, RAW>(rs, c, ring, xmax, hmin, vmax);
                 if (WANT_R) q[ii * QSTRIDE] = r;
             }
+#ifdef ALAC_DIAG
+            st.plain_cycles += clock64() - tA;
+#endif
             spec_unpark<WANT_R, QSTRIDE>(rs, snap, parked, xmax, hmin, q);
             vmax = parked ? 0u : vmax;
         } else {
@@ -247,6 +259,9 @@ __device__ __forceinline__ uint32_t ab_entropy_pass(const alac_decode_params& p,
     int flags = 0;
     int full_left = 0;
     SpecStats st;
+#ifdef ALAC_DIAG
+    st.t_pass = clock64();
+#endif
     Rice rs;
     rs.w0 = rs.w1 = rs.w2 = 0; rs.next = 12; rs.hist = 0; rs.signmod = 0; rs.zrun = 0; rs.nforce = 0;
     rs.ra = rs.ra_sync = lds_addr(sh.rings[g]);
@@ -292,6 +307,9 @@ __device__ __forceinline__ uint32_t ab_entropy_pass(const alac_decode_params& p,
     int endflags = 0;
     bool ended = false;
     int c = 0;
+#ifdef ALAC_DIAG
+    st.setup = clock64() - st.t_pass;
+#endif
     while (c < nchunks) {
         // ---- between stretches: streams that have ended become shadows of the longest one (rare) ----
         {
@@ -337,7 +355,10 @@ __device__ __forceinline__ uint32_t ab_entropy_pass(const alac_decode_params& p,
             const int i0 = c * AB_CHUNK;
             int* q = (sub == 0 && kreal) ? &sh.resq[c & 1][0][g] : &sh.dummy[lane];
             if (i0 < nmax) {
-                const bool fast_chunk = i0 + AB_CHUNK <= knmin - 1;
+                // (a stream may END with the chunk: the reference reads no run symbol behind a stream's last sample, whatever the
+                // history -- AlacFile.cs:231 -- while the speculative step reports one; such a unit is then decoded by rice_step,
+                // which knows.  The generic loop below costs 570 cycles per sample: 36 k cycles per workgroup for cfg2's last chunks)
+                const bool fast_chunk = i0 + AB_CHUNK <= knmin;
 #if defined(ALAC_EXPERIMENT) && ALAC_EXPERIMENT == 2
                 if (fast_chunk) {
                     for (int u = 0; u < AB_CHUNK; u++) q[u * S] = 0;
@@ -356,6 +377,9 @@ __device__ __forceinline__ uint32_t ab_entropy_pass(const alac_decode_params& p,
                         }
                     }
                 } else {      // some stream ends in this chunk (or one sample after it): shadows step with their source
+#ifdef ALAC_DIAG
+                    const long long tS = clock64();
+#endif
                     const int qstride = (sub == 0 && kreal) ? S : 0;
                     for (int ii = 0; ii < AB_CHUNK; ii++) {
                         const int i = i0 + ii;
@@ -363,21 +387,31 @@ __device__ __forceinline__ uint32_t ab_entropy_pass(const alac_decode_params& p,
                         if (i < kn) r = rice_step(rs, kc, kn - 1 - i, i, &flags, kring);
                         q[ii * qstride] = RAW ? ab_zigzag(r) : r;
                     }
+#ifdef ALAC_DIAG
+                    st.slow_chunk += clock64() - tS;
+#endif
                 }
                 rice_sync(rs);
                 if (sub == 0) sh.ring_next[g] = rs.next;
             }
+#ifdef ALAC_DIAG
+            const long long tB = clock64();
+#endif
             wg_sync();  // chunk c is ready for the FIR wave
+#ifdef ALAC_DIAG
+            st.bar_cycles += clock64() - tB;
+#endif
         }
     }
     wg_sync();      // final barrier of the pass (every wave executes nchunks + 1 per pass)
 #ifdef ALAC_DIAG
-    if (p.dbg && lane == 0 && NS == 8) {   // slot 1: plain ok | escape failures; 4: z units | escape-tier units; 5: run failures | redone; 6: full | late run
+    if (p.dbg && lane == 0 && NS == 8) {   // slot 1: plain ok | escape failures; 4: z units | escape-tier units; 5: run failures, redone | cycles in generic chunks; 6: full, late run | pass set-up cycles; 3: barrier waits | cycles inside plain units
         unsigned long long* d = p.dbg + 8 * blockIdx.x;
         d[1] += ((unsigned long long)st.plain_ok << 32) | (unsigned)st.fail_esc;
         d[4] += ((unsigned long long)st.z_units << 32) | (unsigned)st.esc_units;
-        d[5] += ((unsigned long long)st.fail_run << 32) | (unsigned)st.redo;
-        d[6] += ((unsigned long long)st.full_units << 32) | (unsigned)st.late_run;
+        d[5] += ((unsigned long long)st.fail_run << 48) | ((unsigned long long)st.redo << 32) | (unsigned long long)(st.slow_chunk & 0xFFFFFFFFll);
+        d[6] += ((unsigned long long)st.full_units << 48) | ((unsigned long long)st.late_run << 32) | (unsigned long long)(st.setup & 0xFFFFFFFFll);
+        d[3] += ((unsigned long long)st.bar_cycles << 32) | (unsigned long long)(st.plain_cycles & 0xFFFFFFFFll);
     }
 #endif
     rice_sync(rs);

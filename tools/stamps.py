@@ -41,18 +41,22 @@ t0 = s[:, 0].min()
 start = (s[:, 0] - t0).astype(np.float64); end = (s[:, 2] - t0).astype(np.float64)
 dur = end - start
 print(f"kernel {ms:.3f} ms; {len(s)} workgroups stamped; duration cycles: min {dur.min():.0f} median {np.median(dur):.0f} mean {dur.mean():.0f} max {dur.max():.0f}; last end {end.max():.0f}")
-if os.environ.get("ALACGPU_LIB", "").endswith("_diag.so"):
+if "_diag" in os.path.basename(os.environ.get("ALACGPU_LIB", "")):
     # diagnostic build: unit counters of the entropy wave (both passes summed), see SpecStats in alac_kernels.hip
     hi = lambda x: (x >> np.uint64(32)).astype(np.float64)
     lo = lambda x: (x & np.uint64(0xFFFFFFFF)).astype(np.float64)
+    f16 = lambda x, sh: ((x >> np.uint64(sh)) & np.uint64(0xFFFF)).astype(np.float64)
     cols = {"plain_ok": hi(s[:, 1]), "fail_esc": lo(s[:, 1]), "z_units": hi(s[:, 4]), "esc_units": lo(s[:, 4]),
-            "fail_run": hi(s[:, 5]), "redo": lo(s[:, 5]), "full_units": hi(s[:, 6]), "late_run": lo(s[:, 6]),
-            "fir_barrier_wait": s[:, 7].astype(np.float64)}
+            "fail_run": f16(s[:, 5], 48), "redo": f16(s[:, 5], 32), "full_units": f16(s[:, 6], 48), "late_run": f16(s[:, 6], 32),
+            "fir_barrier_wait": s[:, 7].astype(np.float64),
+            # cycle accounts of the entropy wave (both passes): inside the 8 steps of plain units, at chunk barriers, pass set-up,
+            # chunks decoded by the generic step; what is left of `duration` is the code between units and the stamps themselves
+            "cyc_plain_steps": lo(s[:, 3]), "cyc_barrier_wait": hi(s[:, 3]), "cyc_pass_setup": lo(s[:, 6]), "cyc_generic_chunks": lo(s[:, 5])}
     order = np.argsort(dur)
-    print("per-workgroup unit counts      mean   | slowest 5 workgroups")
+    print("per-workgroup unit counts      mean   | fastest 3 workgroups           | slowest 5 workgroups")
     for k, v in cols.items():
-        print(f"  {k:<18s} {v.mean():10.1f}   | " + " ".join(f"{v[i]:9.0f}" for i in order[-5:]))
-    print(f"  {'duration':<18s} {dur.mean():10.0f}   | " + " ".join(f"{dur[i]:9.0f}" for i in order[-5:]))
+        print(f"  {k:<18s} {v.mean():10.1f}   | " + " ".join(f"{v[i]:9.0f}" for i in order[:3]) + "  | " + " ".join(f"{v[i]:9.0f}" for i in order[-5:]))
+    print(f"  {'duration':<18s} {dur.mean():10.0f}   | " + " ".join(f"{dur[i]:9.0f}" for i in order[:3]) + "  | " + " ".join(f"{dur[i]:9.0f}" for i in order[-5:]))
     X = np.stack([np.ones(len(dur)), cols["fail_esc"], cols["esc_units"], cols["z_units"], cols["redo"], cols["full_units"]], axis=1)
     coef, res, *_ = np.linalg.lstsq(X, dur, rcond=None)
     pred = X @ coef
