@@ -1074,14 +1074,22 @@ __device__ __forceinline__ void ab_kernel_body(const alac_decode_params& p) {
 
 }  // namespace
 
+// One kernel entry per object file: the Makefile compiles this source three times (-DALAC_EMIT=1 / 2 / 3), each kernel with
+// the instruction-scheduler settings it measured best with (Makefile: SCHED_*).  Without ALAC_EMIT all three are emitted.
+#if !defined(ALAC_EMIT) || ALAC_EMIT == 1
 // 96 registers for the main kernel: five workgroups per CU instead of four once a batch has more than fit at once
 // (cfg2 at 16384 packets 2.38 -> 2.00 ms, 32768 4.10 -> 3.68; the 44 bytes of scratch are in rarely executed parts, and
 // the small batches did not lose: 4096 packets 0.814 -> 0.804 ms).
 extern "C" __global__ __launch_bounds__(256, 5) void alac_decode_ab_kernel(alac_decode_params p) { ab_kernel_body<8>(p); }
+#endif
+#if !defined(ALAC_EMIT) || ALAC_EMIT == 2
 // LPC orders up to 31 (and the delta mode): two FIR waves in the 16-lane layout with two tap registers, four packets each
 extern "C" __global__ __launch_bounds__(256) void alac_decode_ab32_kernel(alac_decode_params p) { ab_kernel_body<16>(p); }
+#endif
+#if !defined(ALAC_EMIT) || ALAC_EMIT == 3
 // The main kernel's dense arrangement for big batches: 16 packets per 256-thread workgroup: one entropy wave for all 16
 // streams (4 lanes each), one output wave for all 16, two FIR waves of 8 streams -- one wave per SIMD, roles by SIMD and turn
 // as above.  Same results, about a fifth fewer instructions per sample; a step of its entropy wave takes as long as the
 // 8-stream one's, so small (latency-bound) batches gain nothing.
 extern "C" __global__ __launch_bounds__(256, 4) void alac_decode_ab_dense_kernel(alac_decode_params p) { ab_kernel_body<8, 16>(p); }
+#endif
