@@ -925,14 +925,22 @@ __device__ __forceinline__ void ab_output_wave(const alac_decode_params& p, uint
     }
 }
 
-template <int P, int NS = 8>
+// WIDE_ONLY: the main kernel's code inside the SECOND launch, for the groups the first launch left to it because a stream has
+// 9..16 taps (two taps per lane of the FIR wave): that path is a different instruction mix and wants a different
+// instruction-scheduler strategy than the 8-tap path (Makefile: SCHED_*), and a kernel has one.
+#ifndef ALAC_WIDE_SPLIT
+#define ALAC_WIDE_SPLIT 1
+#endif
+template <int P, int NS = 8, bool WIDE_ONLY = false>
 __device__ __forceinline__ void ab_kernel_body(const alac_decode_params& p) {
     static_assert(NS == 8 || (P == 8 && NS == 16), "the dense arrangement exists for the main kernel only");
+    static_assert(!WIDE_ONLY || (P == 8 && NS == 8), "");
     __shared__ __attribute__((aligned(1024))) AbSharedT<NS> sh;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t pkt0 = blockIdx.x * (uint32_t)NS;
-    // ab_flags[group]: 0 = decoded by alac_decode_ab_kernel, 1 = left for alac_decode_ab32_kernel, 2 = decoded by it
-    if (P == 16 && (!p.ab_flags || p.ab_flags[blockIdx.x] == 0u)) return;
+    // ab_flags[group]: 0 = decoded by the first launch (alac_decode_ab_kernel / _dense_kernel); left for the second launch
+    // (alac_decode_ab32_kernel): 1 = to its 32-tap code, 3 = to its copy of the main kernel's two-taps-per-lane code;
+    // 2 / 4 = decoded there.  (The second kernel's entry point looks at the flag and calls the body that goes with it.)
     // every wave reads all 8 headers: pass lengths (uniform over the workgroup) and whether the P8 layout fits
     int n0 = 0, n1 = 0;
     bool bad = false, wide_lane = false;
@@ -981,12 +989,17 @@ __device__ __forceinline__ void ab_kernel_body(const alac_decode_params& p) {
     // some stream (of the block of 8 a FIR wave serves) has more than 8 taps: two taps per lane
     const bool wide = __builtin_amdgcn_ballot_w64(wide_lane && (lane & (NS - 1)) < 8) != 0;
     const bool wide1 = NS > 8 && __builtin_amdgcn_ballot_w64(wide_lane && (lane & (NS - 1)) >= 8) != 0;
-    if (P == 8) {
-        if (p.ab_flags && threadIdx.x == 0) {   // one flag per 8 packets (the 32-tap kernel works in groups of 8)
+    // (8-packet arrangement only: the dense one keeps its two-taps-per-lane groups)
+    const bool hand_over = P == 8 && NS == 8 && !WIDE_ONLY && ALAC_WIDE_SPLIT && p.ab_flags && wide && !fallback;
+    if (P == 8 && !WIDE_ONLY) {
+        if (p.ab_flags && threadIdx.x == 0) {   // one flag per 8 packets (the second launch works in groups of 8)
             const uint32_t f0 = blockIdx.x * (uint32_t)(NS / 8);
-            p.ab_flags[f0] = fallback ? 1u : 0u;
+            p.ab_flags[f0] = fallback ? 1u : hand_over ? 3u : 0u;
             if (NS > 8 && pkt0 + 8u < p.n_packets) p.ab_flags[f0 + 1] = fallback ? 1u : 0u;
         }
+        if (hand_over) return;
+    } else if (WIDE_ONLY) {
+        if (threadIdx.x == 0) p.ab_flags[blockIdx.x] = 4u;
     } else {
         if (!fallback && threadIdx.x == 0) p.ab_flags[blockIdx.x] = 2u;
         // Nothing is launched behind this kernel in auto mode.  What it cannot take would be a two-channel packet without
@@ -1064,7 +1077,7 @@ __device__ __forceinline__ void ab_kernel_body(const alac_decode_params& p) {
         for (int ph = 0; ph < (nch1 > 0 ? 2 : 1); ph++) ab_fir16_wave(p, pkt0, role - 2, lane, sh, ph, ph ? nch1 : nch0);
     } else {
         __builtin_amdgcn_s_setprio(1);   // above the output waves, below the entropy waves (8192 packets: 1.074 -> 1.048 ms, cfg3 3.33 -> 3.25)
-        if (__builtin_expect(!wide, 1)) {
+        if (!WIDE_ONLY && __builtin_expect(!wide, 1)) {
             for (int ph = 0; ph < (nch1 > 0 ? 2 : 1); ph++) ab_fir_wave<NS>(p, pkt0, 0, lane, sh, ph, ph ? nch1 : nch0);
         } else {
             for (int ph = 0; ph < (nch1 > 0 ? 2 : 1); ph++) ab_fir_wave2<NS>(p, pkt0, 0, lane, sh, ph, ph ? nch1 : nch0);
@@ -1084,7 +1097,12 @@ extern "C" __global__ __launch_bounds__(256, 5) void alac_decode_ab_kernel(alac_
 #endif
 #if !defined(ALAC_EMIT) || ALAC_EMIT == 2
 // LPC orders up to 31 (and the delta mode): two FIR waves in the 16-lane layout with two tap registers, four packets each
-extern "C" __global__ __launch_bounds__(256) void alac_decode_ab32_kernel(alac_decode_params p) { ab_kernel_body<16>(p); }
+// -- and the groups of the main kernel with 9..16 taps (see ab_kernel_body: WIDE_ONLY)
+extern "C" __global__ __launch_bounds__(256) void alac_decode_ab32_kernel(alac_decode_params p) {
+    const uint32_t f = p.ab_flags ? p.ab_flags[blockIdx.x] : 0u;
+    if (f == 1u) ab_kernel_body<16>(p);
+    else if (f == 3u) ab_kernel_body<8, 8, true>(p);
+}
 #endif
 #if !defined(ALAC_EMIT) || ALAC_EMIT == 3
 // The main kernel's dense arrangement for big batches: 16 packets per 256-thread workgroup: one entropy wave for all 16
