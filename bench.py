@@ -193,7 +193,7 @@ def reduce_sum(torch, dist, cdev, *vals):
 
 def kernel_source_sha():
     h = hashlib.sha256()
-    for fn in ("alac_kernels.hip", "alac_device.h", "alac_kernels.h"):
+    for fn in ("alac_kernels.hip", "alac_device.h", "alac_kernels.h", "Makefile"):   # (the Makefile holds the scheduler flags)
         h.update(open(os.path.join(ROOT, "alac.net_amd", "csrc", fn), "rb").read())
     return h.hexdigest()[:16]
 
