@@ -55,6 +55,13 @@ __global__ __launch_bounds__(64) void kern(unsigned long long* out, int* sink, i
         if (K == 37) { REP16(asm volatile("v_subb_co_u32 %0, vcc, %0, %4, vcc\n v_subb_co_u32 %1, vcc, %1, %4, vcc\n v_subb_co_u32 %2, vcc, %2, %4, vcc\n v_subb_co_u32 %3, vcc, %3, %4, vcc" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(seed) : "vcc");) }
         if (K == 38) { REP16(asm volatile("v_max_i32 %0, %0, %4\n v_max_i32 %1, %1, %4\n v_max_i32 %2, %2, %4\n v_max_i32 %3, %3, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(seed));) }
         if (K == 39) { REP16(asm volatile("v_add_u32_dpp %0, %0, %0 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_u32_dpp %1, %1, %1 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_u32_dpp %2, %2, %2 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_u32_dpp %3, %3, %3 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(seed));) }
+        // control flow (round 2): what a hop costs a wave that is alone on its SIMD.  The figures are per pair / group below.
+        if (K == 40) { REP16(asm volatile("v_add_u32 %0, %0, %1\n s_branch 1f\n s_nop 0\n s_nop 0\n1:" : "+v"(a) : "v"(b));) }                 // taken branch, target in the same cache line
+        if (K == 41) { REP16(asm volatile("v_add_u32 %0, %0, %1\n s_branch 1f\n .fill 256, 4, 0xbf800000\n1:" : "+v"(a) : "v"(b));) }       // taken branch over 1 KiB of s_nop
+        if (K == 42) { REP16(asm volatile("v_cmp_lt_i32 vcc, %0, %1\n s_cbranch_vccnz 1f\n s_nop 0\n1:\n v_add_u32 %0, %0, %1" : "+v"(a) : "v"(b) : "vcc");) }   // compare -> conditional branch, NOT taken (a > b)
+        if (K == 43) { REP16(asm volatile("v_cmp_gt_i32 vcc, %0, %1\n s_cbranch_vccnz 1f\n .fill 64, 4, 0xbf800000\n1:\n v_add_u32 %0, %0, %1" : "+v"(a) : "v"(b) : "vcc");) }   // ... taken, over 256 B
+        if (K == 44) { REP16(asm volatile("v_cmp_lt_i32 vcc, %0, %1\n s_cmp_lg_u64 vcc, 0\n s_cbranch_scc1 1f\n s_nop 0\n1:\n v_add_u32 %0, %0, %1" : "+v"(a) : "v"(b) : "vcc", "scc");) }   // ballot != 0 idiom, not taken
+        if (K == 45) { REP16(asm volatile("v_add_u32 %0, %0, %1\n s_nop 0" : "+v"(a) : "v"(b));) }                                              // reference: the add with one s_nop
         if (K == 14) { REP16(asm volatile("v_lshlrev_b64 %0, %1, %0" : "+v"(*(long long*)&lds[0]) : "v"(b));) }
     }
 done:
@@ -125,5 +132,12 @@ int main() {
     run<37>("4x v_subb_co_u32", 4, d_out, d_sink);
     run<38>("4x v_max_i32", 4, d_out, d_sink);
     run<39>("4x v_add_u32_dpp (own chain; hazard nops NOT added)", 4, d_out, d_sink);
+    printf("control flow, per group (the v_add included):\n");
+    run<45>("v_add + s_nop (reference)", 1, d_out, d_sink);
+    run<40>("v_add + s_branch (near)", 1, d_out, d_sink);
+    run<41>("v_add + s_branch over 1 KiB", 1, d_out, d_sink);
+    run<42>("v_cmp + cbranch NOT taken + v_add", 1, d_out, d_sink);
+    run<43>("v_cmp + cbranch taken 256 B + v_add", 1, d_out, d_sink);
+    run<44>("v_cmp + s_cmp + cbranch not taken + v_add", 1, d_out, d_sink);
     return 0;
 }
