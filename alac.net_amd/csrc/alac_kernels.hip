@@ -209,9 +209,11 @@ __device__ __forceinline__ int mirror_i(int v, int src) { return __shfl(v, src, 
 // wave un-mixes it with the parked A samples (read back one chunk ahead) and stores the PCM.  Both passes keep every
 // lane of the FIR wave busy (8 streams x 8 taps), which the one-pass layout only manages with both channels at once.
 // One-channel and uncompressed packets finish in pass 0.
-// alac_decode_ab_kernel takes the groups of 8 packets whose streams have LPC order 1..16 (one or two taps per lane of
-// the FIR wave) and flags the others (alac_decode_params::ab_flags) for alac_decode_ab32_kernel, launched behind it:
-// the same with two FIR waves in the 16-lanes-per-stream layout with two tap registers (any order, delta mode).
+// alac_decode_ab_kernel takes the groups of 8 packets whose streams have LPC order 1..8 (one tap per lane of the FIR
+// wave) and flags the others (alac_decode_params::ab_flags) for alac_decode_ab32_kernel, launched behind it: that one runs
+// this same code with two taps per lane for groups with orders 9..16 (its own object file: that path wants another
+// instruction-scheduler strategy, see the Makefile), and for everything else (any order, delta mode) the variant with two
+// FIR waves in the 16-lanes-per-stream layout with two tap registers.  (The dense arrangement keeps orders 1..16.)
 // Parking place: ints [n, 2n) of the slot (slot_ints >= 2n for two channels).  The final stores of sample i touch
 // at most int 2i+1 (int32 output) or byte 6i+5 (packed), always below the parked samples not yet consumed.
 // ===================================================================================================================
