@@ -52,6 +52,8 @@ def test_single_gpu_line_has_the_contract_keys_and_parity():
     assert j["roofline"]["bound"] == "hbm" and 0 < j["roofline"]["frac"] < 1
     assert j["cpu_baseline"]["cores"] == 1 and j["cpu_baseline"]["kind"] == "port"
     assert j["host_path"]["int32_pinned_ms"] > 0 and j["host_path"]["decode_frame_ms"] > 0
+    # two batches in flight on two streams: the same outputs, reported beside `value`, never as it
+    assert j["two_in_flight"]["same_output_as_value_run"] is True and j["two_in_flight"]["value"] > 0
 
 
 @pytest.mark.gpu

@@ -14,7 +14,7 @@ for r in $(seq 1 $R); do
     line="$(basename $lib .so)${envset:+[$envset]}"
     for spec in $SPECS; do
       c=${spec%%:*}; n=${spec##*:}
-      ms=$(env $envset timeout -k 5 120 python3 bench.py --config $c --packets $n --steps 20 --warmup 3 --no-cpu-baseline --no-host-path 2>/dev/null | python3 -c "import sys,json; j=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('%.4f%s' % (j['roofline']['kernel_ms'], '' if j['status_ok'] else '!BAD'))")
+      ms=$(env $envset timeout -k 5 120 python3 bench.py --config $c --packets $n --steps 20 --warmup 3 --no-cpu-baseline --no-host-path --no-in-flight 2>/dev/null | python3 -c "import sys,json; j=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('%.4f%s' % (j['roofline']['kernel_ms'], '' if j['status_ok'] else '!BAD'))")
       line="$line  cfg$c@$n=$ms"
     done
     echo "$line"

@@ -6,7 +6,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/icache; mkdir -p $OUT
 for L in "$@"; do
   export ALACGPU_LIB=$GRAFT_REPO_ROOT/$L
   name=$(basename $L .so)
-  timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d $OUT/$name -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-path --no-big-batch --no-extra > $OUT/$name.log 2>&1 || { tail -5 $OUT/$name.log; exit 3; }
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d $OUT/$name -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-path --no-big-batch --no-in-flight --no-extra > $OUT/$name.log 2>&1 || { tail -5 $OUT/$name.log; exit 3; }
   python3 - "$OUT/$name" "$name" <<'P'
 import sys, glob, csv, collections
 d, name = sys.argv[1], sys.argv[2]
