@@ -686,6 +686,8 @@ __device__ __forceinline__ void fir8_step(Fir8Lane& f, int err, int i, bool acti
     p = wadd(p, dpp0<DPP_QUAD_2301>(p));
     p = wadd(p, __builtin_amdgcn_update_dpp(0, p, DPP_ROW_ROR4, 0xF, 0xF, false));
     p = wadd(p, __builtin_amdgcn_update_dpp(0, p, DPP_ROW_ROR8, 0xF, 0xF, false));
+    asm("" : "+v"(p));   // keep this a one-instruction v_add_u32_dpp: merged with the rounding term into a v_add3 it needs a
+                         // separate v_mov_dpp whose old-value register has to be zeroed first (one more instruction per step)
     int out = __builtin_amdgcn_sbfe(wadd(wadd(wadd(f.rnd, p) >> f.q, f.base), err), 0, f.rss);  // :306-310
     bool general = true;
     if (GENERIC) {
