@@ -1089,13 +1089,17 @@ __device__ __forceinline__ void ab_kernel_body(const alac_decode_params& p) {
 
 }  // namespace
 
-// One kernel entry per object file: the Makefile compiles this source three times (-DALAC_EMIT=1 / 2 / 3), each kernel with
-// the instruction-scheduler settings it measured best with (Makefile: SCHED_*).  Without ALAC_EMIT all three are emitted.
+// One kernel entry per object file: the Makefile compiles this source four times (-DALAC_EMIT=1 .. 4), each kernel with
+// the instruction-scheduler settings it measured best with (Makefile: SCHED_*).  Without ALAC_EMIT all of them are emitted.
 #if !defined(ALAC_EMIT) || ALAC_EMIT == 1
-// 96 registers for the main kernel: five workgroups per CU instead of four once a batch has more than fit at once
-// (cfg2 at 16384 packets 2.38 -> 2.00 ms, 32768 4.10 -> 3.68; the 44 bytes of scratch are in rarely executed parts, and
-// the small batches did not lose: 4096 packets 0.814 -> 0.804 ms).
-extern "C" __global__ __launch_bounds__(256, 5) void alac_decode_ab_kernel(alac_decode_params p) { ab_kernel_body<8>(p); }
+// The main kernel for batches whose workgroups fit the chip four per CU (up to 10240 packets): 128 registers, nothing spilled.
+extern "C" __global__ __launch_bounds__(256, 4) void alac_decode_ab_kernel(alac_decode_params p) { ab_kernel_body<8>(p); }
+#endif
+#if !defined(ALAC_EMIT) || ALAC_EMIT == 4
+// The same with 96 registers, for the batches in between (10241 .. 12288 packets): five workgroups per CU instead of four
+// once a batch has more than fit at once (12288 packets: 1.43 against 1.71 ms); the scratch it then needs (the max-ilp
+// scheduling raises the register pressure: 116 bytes per lane) costs the small batches 1.5 %, which is why they have their own.
+extern "C" __global__ __launch_bounds__(256, 5) void alac_decode_ab5_kernel(alac_decode_params p) { ab_kernel_body<8>(p); }
 #endif
 #if !defined(ALAC_EMIT) || ALAC_EMIT == 2
 // LPC orders up to 31 (and the delta mode): two FIR waves in the 16-lane layout with two tap registers, four packets each

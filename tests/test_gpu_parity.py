@@ -19,13 +19,16 @@ def pkg():
     return p
 
 
-@pytest.fixture(autouse=True, params=["auto", "dense"])
+@pytest.fixture(autouse=True, params=["auto", "dense", "ab5"])
 def arrangement(request, monkeypatch):
-    """Every test of this module runs twice: with the library's own choice between the main kernel's two arrangements
-    (8 packets per workgroup below 12289 packets per batch) and with the 16-packet ("dense") arrangement forced
-    (ALACGPU_DENSE is read when a context is created)."""
+    """Every test of this module runs three times: with the library's own choice between the builds of the main kernel
+    (8 packets per workgroup: 128 registers up to 10240 packets per batch, 96 registers up to 12288; 16 packets per workgroup
+    above), with the 16-packet ("dense") arrangement forced and with the 96-register build of the 8-packet one forced
+    (ALACGPU_DENSE = 1 / 2, read when a context is created)."""
     if request.param == "dense":
         monkeypatch.setenv("ALACGPU_DENSE", "1")
+    elif request.param == "ab5":
+        monkeypatch.setenv("ALACGPU_DENSE", "2")
     else:
         monkeypatch.delenv("ALACGPU_DENSE", raising=False)
     return request.param
