@@ -930,9 +930,6 @@ __device__ __forceinline__ void ab_output_wave(const alac_decode_params& p, uint
 // WIDE_ONLY: the main kernel's code inside the SECOND launch, for the groups the first launch left to it because a stream has
 // 9..16 taps (two taps per lane of the FIR wave): that path is a different instruction mix and wants a different
 // instruction-scheduler strategy than the 8-tap path (Makefile: SCHED_*), and a kernel has one.
-#ifndef ALAC_MIRROR_TURNS
-#define ALAC_MIRROR_TURNS 0
-#endif
 #ifndef ALAC_WIDE_SPLIT
 #define ALAC_WIDE_SPLIT 1
 #endif
@@ -1057,17 +1054,7 @@ __device__ __forceinline__ void ab_kernel_body(const alac_decode_params& p) {
             // the 32-tap kernel has four working waves, two of them FIR: with up to two workgroups per CU a step of two
             // SIMDs per turn pairs every FIR wave with an entropy or an output wave instead of another FIR wave
             const uint32_t step = (P == 16 && gridDim.x <= 512u) ? 2u : 1u;
-            const uint32_t turn = sh.ring_next[NS - 1];
-            role = (int)((my_simd - step * turn) & 3u);
-#if ALAC_MIRROR_TURNS
-            if (P == 8 && NS == 8) {
-                // 8-packet arrangement (three working waves): odd turns take the SIMDs in the opposite order, so that with
-                // two workgroups on a CU BOTH entropy waves have a SIMD to themselves (0 and 3) and the output waves share with
-                // the FIR waves (1 and 2); turns 2 and 3 the same, rotated by two: four workgroups load every SIMD alike.
-                const uint32_t s2 = (my_simd - 2u * (turn >> 1)) & 3u;
-                role = (turn & 1u) ? (int)(3u - s2) : (int)s2;
-            }
-#endif
+            role = (int)((my_simd - step * sh.ring_next[NS - 1]) & 3u);
         }
     }
     if (P == 8 && NS == 8 && role == 3) return;     // the main kernel's fourth wave was only there to claim the fourth SIMD
