@@ -223,12 +223,13 @@ def test_full_size_cfg2_roundtrip_property(pkg, synth):
     assert np.array_equal(pcm, b["pcm"])
 
 
-@pytest.mark.parametrize("stereo", [True, False])
-def test_auto_kernel_choice_above_the_big_batch_threshold(pkg, oracle, synth, stereo):
-    # between 10241 and 20480 packets the library takes one-channel cfgs to the 16-packet split workgroups; two-channel cfgs
-    # stay with the two-pass kernels: short packets keep the oracle fast; ragged sample counts and a last, partly filled
-    # workgroup included
-    count = 5203 if stereo else 10243
+@pytest.mark.parametrize("count", [10240, 10243, 12291])
+def test_auto_kernel_choice_at_the_batch_size_thresholds(pkg, oracle, synth, count, monkeypatch):
+    # one launch per batch (a single host range), so that the batch size decides: up to 10240 packets the 128-register build of
+    # the 8-packet arrangement, 10241..12288 the 96-register one, above that the 16-packet arrangement (alacgpu_api.hip: launch).
+    # Short packets keep the oracle fast; ragged sample counts and a last, partly filled workgroup included.
+    monkeypatch.setenv("ALACGPU_HOST_CHUNKS", "1")
+    stereo = count % 2 == 1
     d = synth.packet_descs(count, n=96, max_samples_per_frame=4096, stereo=int(stereo))
     rng = np.random.default_rng(count)
     d["n"] = rng.integers(1, 129, count)
