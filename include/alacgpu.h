@@ -124,6 +124,9 @@ int alacgpu_decode_batch_sharded(alacgpu_ctx* const* ctxs, uint32_t n_ctxs, cons
  * Outputs as above; d_out_bytes / d_out_samples may be NULL.  Up to 8 calls may be in flight at once on one ctx, on
  * the same or on different streams (each owns its scratch until it has finished; a ninth call waits for the oldest).
  * The caller keeps every buffer alive and unchanged until the stream has passed the call.
+ * Throughput: a launch of a few thousand packets is bound by the length of one packet's serial chain, not by the chip; a
+ * caller with a stream of such batches keeps TWO in flight on two streams (0.78 -> 0.50 ms per batch of 4096 packets, DESIGN.md
+ * section 4; streams that share one of the runtime's hardware queues do not overlap) -- or makes its batches bigger.
  */
 int alacgpu_decode_batch_device(alacgpu_ctx* ctx, const void* d_blob, uint64_t blob_bytes, const void* d_offsets,
                                 const void* d_sizes, const void* d_cfg_idx, uint32_t n_packets, void* d_pcm_out,
