@@ -52,7 +52,8 @@ struct alac_decode_params {
 #ifdef __HIPCC__
 // two passes (channel A, then B), 8 packets / 256-thread workgroup (three working waves), LPC orders 1..16
 extern "C" __global__ void alac_decode_ab_kernel(alac_decode_params p);
-extern "C" __global__ void alac_decode_ab5_kernel(alac_decode_params p);   // the same with 96 registers (five workgroups per CU)
+extern "C" __global__ void alac_decode_ab5_kernel(alac_decode_params p);
+extern "C" __global__ void alac_decode_ab_small_kernel(alac_decode_params p);   // the same with 16-step units (batches up to 4096 packets)   // the same with 96 registers (five workgroups per CU)
 // the same for everything else (LPC orders 17..31, delta mode, order 0): two FIR waves (16-lane layout, 2 tap registers)
 extern "C" __global__ void alac_decode_ab32_kernel(alac_decode_params p);
 // the main kernel with 16 packets / 320-thread workgroup (one entropy wave for 16 streams): big batches

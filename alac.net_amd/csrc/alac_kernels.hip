@@ -1089,11 +1089,18 @@ __device__ __forceinline__ void ab_kernel_body(const alac_decode_params& p) {
 
 }  // namespace
 
-// One kernel entry per object file: the Makefile compiles this source four times (-DALAC_EMIT=1 .. 4), each kernel with
+// One kernel entry per object file: the Makefile compiles this source five times (-DALAC_EMIT=1 .. 5), each kernel with
 // the instruction-scheduler settings it measured best with (Makefile: SCHED_*).  Without ALAC_EMIT all of them are emitted.
 #if !defined(ALAC_EMIT) || ALAC_EMIT == 1
 // The main kernel for batches whose workgroups fit the chip four per CU (up to 10240 packets): 128 registers, nothing spilled.
 extern "C" __global__ __launch_bounds__(256, 4) void alac_decode_ab_kernel(alac_decode_params p) { ab_kernel_body<8>(p); }
+#endif
+#if !defined(ALAC_EMIT) || ALAC_EMIT == 5
+// The same as alac_decode_ab_kernel, its object compiled with speculative units of 16 steps (-DALAC_SPEC_UNIT=16), for batches
+// of up to 4096 packets: the entropy wave's straight-line blocks are twice as long and the code between units runs half as
+// often (every workgroup -3 %), a failed unit costs twice as much (the slowest workgroup -1 %): -2.2 % where the launch is
+// bound by one packet's chain, +2 % from 5120 packets on, where wasted instructions count.
+extern "C" __global__ __launch_bounds__(256, 4) void alac_decode_ab_small_kernel(alac_decode_params p) { ab_kernel_body<8>(p); }
 #endif
 #if !defined(ALAC_EMIT) || ALAC_EMIT == 4
 // The same with 96 registers, for the batches in between (10241 .. 12288 packets): five workgroups per CU instead of four

@@ -19,6 +19,7 @@ static_assert(sizeof(alacgpu_cfg) == sizeof(alacgpu_cfg_dev), "cfg layouts must 
 namespace {
 
 constexpr int N_SLOTS = 8;          // launch pairs that may be in flight at once on one ctx (any streams)
+constexpr uint32_t AB_SMALL_MAX_PACKETS = 4096;  // up to here: the build with 16-step speculative units (latency-bound launches)
 constexpr uint32_t AB5_MIN_PACKETS = 10241;     // above: the 96-register build of the 8-packet arrangement (five workgroups per CU)
 constexpr uint32_t DENSE_MIN_PACKETS = 12289;   // measured cross-over of the two arrangements of the main kernel
 constexpr int N_HOST_STREAMS = 4;   // chunks of the host-buffer pipeline (H2D k+1 || decode k || D2H k-1)
@@ -48,7 +49,8 @@ struct alacgpu_ctx {
     uint32_t out_format = 0;           // 0 int32 per sample, 1 packed little-endian PCM
     int host_chunks = 0;               // 0 auto; 1..N_HOST_STREAMS forced (ALACGPU_HOST_CHUNKS, A/B only)
     int dense = -1;                    // main kernel's 16-packet workgroups: -1 auto (by batch size), 0 never, 1 always (ALACGPU_DENSE; A/B and tests)
-                                       // 2 (ALACGPU_DENSE=2): never, and the 96-register build of the 8-packet arrangement whatever the batch size
+                                       // 2 / 3 / 4 (ALACGPU_DENSE=..): never, and the 96-register build / the 16-step-unit build / the plain
+                                       // 128-register build of the 8-packet arrangement whatever the batch size (tests)
     uint32_t* d_cu_arrivals = nullptr; // per-CU workgroup counters (alac_decode_params::cu_arrivals)
     // grow-only device workspace for the host-buffer entry points
     void* d_ws = nullptr;
@@ -116,8 +118,12 @@ int launch(alacgpu_ctx* ctx, const alac_decode_params& p_in, hipStream_t stream)
     if (dense)
         HIP_TRY(ctx, hipLaunchKernel((const void*)alac_decode_ab_dense_kernel, dim3((uint32_t)((groups + 1) / 2)), dim3(256), kargs, 0, stream));
     else
-        HIP_TRY(ctx, hipLaunchKernel(p.n_packets >= AB5_MIN_PACKETS || ctx->dense == 2 ? (const void*)alac_decode_ab5_kernel : (const void*)alac_decode_ab_kernel,
-                                     dim3((uint32_t)groups), dim3(256), kargs, 0, stream));
+    {
+        const void* k = (const void*)alac_decode_ab_kernel;
+        if (ctx->dense == 2 || (ctx->dense <= 0 && p.n_packets >= AB5_MIN_PACKETS)) k = (const void*)alac_decode_ab5_kernel;
+        else if (ctx->dense == 3 || (ctx->dense <= 0 && p.n_packets <= AB_SMALL_MAX_PACKETS)) k = (const void*)alac_decode_ab_small_kernel;
+        HIP_TRY(ctx, hipLaunchKernel(k, dim3((uint32_t)groups), dim3(256), kargs, 0, stream));
+    }
     HIP_TRY(ctx, hipLaunchKernel((const void*)alac_decode_ab32_kernel, dim3((uint32_t)groups), dim3(256), kargs, 0, stream));
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(sl.ev1, stream));
@@ -240,7 +246,7 @@ int alacgpu_create(const alacgpu_cfg* cfgs, uint32_t n_cfgs, int device, alacgpu
     if (!ctx) return ALACGPU_ERR_NO_MEMORY;
     ctx->device = device;
     ctx->n_cfgs = n_cfgs;
-    if (const char* v = std::getenv("ALACGPU_DENSE")) ctx->dense = std::max(0, std::min(std::atoi(v), 2));
+    if (const char* v = std::getenv("ALACGPU_DENSE")) ctx->dense = std::max(0, std::min(std::atoi(v), 4));
     if (const char* v = std::getenv("ALACGPU_HOST_CHUNKS")) ctx->host_chunks = std::max(0, std::min(std::atoi(v), N_HOST_STREAMS));
     int rc = ALACGPU_OK;
     do {

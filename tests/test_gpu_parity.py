@@ -19,16 +19,19 @@ def pkg():
     return p
 
 
-@pytest.fixture(autouse=True, params=["auto", "dense", "ab5"])
+@pytest.fixture(autouse=True, params=["auto", "dense", "ab5", "ab"])
 def arrangement(request, monkeypatch):
-    """Every test of this module runs three times: with the library's own choice between the builds of the main kernel
-    (8 packets per workgroup: 128 registers up to 10240 packets per batch, 96 registers up to 12288; 16 packets per workgroup
-    above), with the 16-packet ("dense") arrangement forced and with the 96-register build of the 8-packet one forced
-    (ALACGPU_DENSE = 1 / 2, read when a context is created)."""
+    """Every test of this module runs four times: with the library's own choice between the builds of the main kernel
+    (8 packets per workgroup: 16-step units up to 4096 packets per batch -- what the small test batches get --, 8-step units
+    with 128 registers up to 10240, with 96 registers up to 12288; 16 packets per workgroup above), with the 16-packet ("dense")
+    arrangement forced, with the 96-register build and with the 128-register 8-step build of the 8-packet one forced
+    (ALACGPU_DENSE = 1 / 2 / 4, read when a context is created)."""
     if request.param == "dense":
         monkeypatch.setenv("ALACGPU_DENSE", "1")
     elif request.param == "ab5":
         monkeypatch.setenv("ALACGPU_DENSE", "2")
+    elif request.param == "ab":
+        monkeypatch.setenv("ALACGPU_DENSE", "4")
     else:
         monkeypatch.delenv("ALACGPU_DENSE", raising=False)
     return request.param
@@ -223,10 +226,11 @@ def test_full_size_cfg2_roundtrip_property(pkg, synth):
     assert np.array_equal(pcm, b["pcm"])
 
 
-@pytest.mark.parametrize("count", [10240, 10243, 12291])
+@pytest.mark.parametrize("count", [4096, 4097, 10240, 10243, 12291])
 def test_auto_kernel_choice_at_the_batch_size_thresholds(pkg, oracle, synth, count, monkeypatch):
-    # one launch per batch (a single host range), so that the batch size decides: up to 10240 packets the 128-register build of
-    # the 8-packet arrangement, 10241..12288 the 96-register one, above that the 16-packet arrangement (alacgpu_api.hip: launch).
+    # one launch per batch (a single host range), so that the batch size decides: up to 4096 packets the build with 16-step units,
+    # up to 10240 the 128-register build of the 8-packet arrangement, 10241..12288 the 96-register one, above that the 16-packet
+    # arrangement (alacgpu_api.hip: launch).
     # Short packets keep the oracle fast; ragged sample counts and a last, partly filled workgroup included.
     monkeypatch.setenv("ALACGPU_HOST_CHUNKS", "1")
     stereo = count % 2 == 1

@@ -64,8 +64,8 @@ def main():
         b["slot_ints"] = int(d["n"].max()) * nc          # (one-channel elements in a two-channel stream still fill two channels)
         o = orc.decode_batch(orc.make_cfgs(cfgs), b["blob"], b["offsets"], b["sizes"], None, b["slot_ints"], n_threads=8)
         assert (o[3] == 0).all(), o[3]
-        for variant in ("8-packet", "dense", "8-packet-96reg"):   # the builds of the main kernel (ALACGPU_DENSE is read at create time)
-            os.environ["ALACGPU_DENSE"] = {"8-packet": "0", "dense": "1", "8-packet-96reg": "2"}[variant]
+        for variant in ("8-packet-16step", "dense", "8-packet-96reg", "8-packet"):   # the builds of the main kernel (ALACGPU_DENSE is read at create time)
+            os.environ["ALACGPU_DENSE"] = {"8-packet-16step": "3", "dense": "1", "8-packet-96reg": "2", "8-packet": "4"}[variant]
             with pkg.AlacGpuContext(cfgs) as ctx:
                 g = ctx.decode_batch(b["blob"], b["offsets"], b["sizes"], None, b["slot_ints"])
                 assert np.array_equal(g[3], o[3]) and np.array_equal(g[1], o[1]) and np.array_equal(g[2], o[2]), (rounds, variant)
@@ -91,7 +91,7 @@ def main():
         if time.time() - last_note > 30:    # a long run has to show signs of life (gpurun kills silent commands)
             last_note = time.time()
             print(f"... {rounds} rounds, {packets} packets, {time.time() - t0:.0f} s", flush=True)
-    print(f"stress ok: {rounds} rounds, {packets} packets x 3 builds of the main kernel, {time.time() - t0:.0f} s, seed {seed}, {skipped} recipes skipped")
+    print(f"stress ok: {rounds} rounds, {packets} packets x 4 builds of the main kernel, {time.time() - t0:.0f} s, seed {seed}, {skipped} recipes skipped")
 
 
 if __name__ == "__main__":
