@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json's metric: decoded PCM Msamples/s on batched frames.
 
-A "step" is one pass of the hot path (alac_decode_ab_kernel + alac_decode_ab32_kernel through the C ABI's
+A "step" is one pass of the hot path (alac_decode_ab_small_kernel + alac_decode_ab32_kernel through the C ABI's
 alacgpu_decode_batch_device) over one batch of synthetic packets already resident in HBM.
 Workload of `value` at every N = BASELINE configs[1] ("cfg2"): 4 096 synthetic 16-bit stereo packets per GPU,
 4096 samples/frame, LPC order 8.  N>1: one process per GPU, every rank decodes its own shard (weak scaling, no data-path
@@ -423,14 +423,18 @@ def main():
             big_batch = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     if rank == 0:
-        kernel_name = "alac_decode_ab_kernel"
+        # the main kernel's build by batch size (alacgpu_api.hip: launch): 16-step units up to 4096 packets, 8-step units with 128
+        # registers up to 10240, with 96 registers up to 12288, 16 packets per workgroup above
+        first = ("alac_decode_ab_small_kernel" if n_packets <= 4096 else "alac_decode_ab_kernel" if n_packets <= 10240
+                 else "alac_decode_ab5_kernel" if n_packets <= 12288 else "alac_decode_ab_dense_kernel")
+        kernel_name = first
         if args.config == 3:
             # LPC order 16: two taps per lane of the FIR wave -- the main kernel's code, compiled into the second launch
-            kernel_name = "alac_decode_ab32_kernel (the main kernel's two-taps-per-lane code; behind alac_decode_ab_kernel)"
+            kernel_name = f"alac_decode_ab32_kernel (the main kernel's two-taps-per-lane code; behind {first})"
         if args.config == 5:
             # LPC orders above 16 in (nearly) every group of 8 packets: the work is done by the 32-tap arrangement launched
             # behind the main two-pass kernel
-            kernel_name = "alac_decode_ab32_kernel (behind alac_decode_ab_kernel)"
+            kernel_name = f"alac_decode_ab32_kernel (behind {first})"
         # HBM traffic comes from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read in-process): the committed
         # measurement of the same workload, valid only for the kernel sources it was taken with
         traffic, traffic_note = None, None
