@@ -481,6 +481,9 @@ __device__ __forceinline__ void ab_entropy_wave(const alac_decode_params& p, uin
 // FIR wave, P8 layout (alac_device.h: fir8_step): 8 lanes per stream, the two parities of a row of 16 lanes hold the SAME
 // channel of two different packets, so one wave serves the 8 streams of a pass.
 // w: which block of 8 streams of the workgroup this wave serves (always 0 when NS == 8).
+#ifndef ALAC_FIR_WHOLE_CHUNK
+#define ALAC_FIR_WHOLE_CHUNK 1
+#endif
 template <int NS>
 __device__ __forceinline__ void ab_fir_wave(const alac_decode_params& p, uint32_t pkt0, int w, int lane, AbSharedT<NS>& sh, int ph, int nchunks) {
     constexpr int S = NS;
@@ -518,6 +521,23 @@ __device__ __forceinline__ void ab_fir_wave(const alac_decode_params& p, uint32_
         // ends, and the warm-up, take the masked steps
         const int* q = (i0 < n_row) ? &sh.resq[c & 1][0][g] : qzero;
         const bool clean = __builtin_amdgcn_ballot_w64(i0 < n_row && i0 + AB_CHUNK > n_row) == 0;
+#if !defined(ALAC_EXPERIMENT) && ALAC_FIR_WHOLE_CHUNK
+        if (__builtin_expect(clean && i0 > 8 && i0 + AB_CHUNK <= nmax, 1)) {
+            // the common chunk as ONE straight-line block of 32 steps (this wave, too, pays for every block boundary)
+#pragma unroll
+            for (int half = 0; half < AB_CHUNK / 8; half++) {
+                int err = q[(8 * half) * S];
+#pragma unroll
+                for (int ii = 0; ii < 8; ii++) {
+                    const int en = q[(8 * half + (ii < 7 ? ii + 1 : ii)) * S];
+                    fir8_step<false, true>(f, err, i0 + 8 * half + ii, true);
+                    err = en;
+                }
+                sh.outq[c & 1][half][64 * w + lane] = f.hist;
+            }
+            continue;
+        }
+#endif
 #pragma unroll
         for (int half = 0; half < AB_CHUNK / 8; half++) {
             const int ih = i0 + 8 * half;
