@@ -607,6 +607,22 @@ __device__ __forceinline__ void ab_fir_wave2(const alac_decode_params& p, uint32
         wg_sync();  // wait for chunk c
         const int* q = (i0 < n_row) ? &sh.resq[c & 1][0][g] : qzero;    // see ab_fir_wave
         const bool clean = __builtin_amdgcn_ballot_w64(i0 < n_row && i0 + AB_CHUNK > n_row) == 0;
+#if ALAC_FIR_WHOLE_CHUNK
+        if (__builtin_expect(clean && i0 > 16 && i0 + AB_CHUNK <= nmax, 1)) {     // see ab_fir_wave
+#pragma unroll
+            for (int half = 0; half < AB_CHUNK / 8; half++) {
+                int err = q[(8 * half) * S];
+#pragma unroll
+                for (int ii = 0; ii < 8; ii++) {
+                    const int en = q[(8 * half + (ii < 7 ? ii + 1 : ii)) * S];
+                    fir8x2_step<false, true>(f, err, i0 + 8 * half + ii, true);
+                    err = en;
+                }
+                sh.outq[c & 1][half][64 * w + lane] = f.hist[0];
+            }
+            continue;
+        }
+#endif
 #pragma unroll
         for (int half = 0; half < AB_CHUNK / 8; half++) {
             const int ih = i0 + 8 * half;
