@@ -253,6 +253,9 @@ typedef AbSharedT<8> AbShared;
 // and converts it, fir8_step<.., true>): the inverse of r = (dv >> 1) ^ -(dv & 1) for what rice_step hands back.
 __device__ __forceinline__ int ab_zigzag(int r) { return (int)(((uint32_t)r << 1) ^ (uint32_t)(r >> 31)); }
 
+#ifndef ALAC_FAST_CHUNK_LOOP
+#define ALAC_FAST_CHUNK_LOOP 1
+#endif
 template <bool RAW, int NS>
 __device__ __forceinline__ uint32_t ab_entropy_pass(const alac_decode_params& p, AbSharedT<NS>& sh, const Meta& m, const RiceCfg& rc, int init_hist,
                                     uint32_t startbit, bool stream_on, int g, int sub, int lane, int nchunks, int* flags_out) {
@@ -353,6 +356,39 @@ __device__ __forceinline__ uint32_t ab_entropy_pass(const alac_decode_params& p,
         const uint32_t kring = mring & ~(uint32_t)RING_MASK;   // (a no-op: rings are 1 KiB aligned -- but the compiler must see it to fold the address into one v_bitop3)
         const int kn = n_eff, knmin = nmin;
         const bool kreal = real;
+#if ALAC_FAST_CHUNK_LOOP && !defined(ALAC_EXPERIMENT)
+        // The chunks that lie wholly inside every stream (all but the last one or two of a stretch) in a loop of their own: nothing
+        // to decide per chunk (this wave pays for every block boundary: see the FIR waves).
+        {
+            int* const qa = (sub == 0 && kreal) ? &sh.resq[0][0][g] : &sh.dummy[lane];
+            const int qodd = (sub == 0 && kreal) ? AB_CHUNK * S : 0;
+            const int cf_end = min(c_stop, knmin / AB_CHUNK);
+            for (; c < cf_end; c++) {
+                const int i0 = c * AB_CHUNK;
+                int* q = qa + (c & 1) * qodd;
+#pragma unroll
+                for (int u = 0; u < AB_CHUNK; u += SPEC_UNIT) {
+                    const bool redo = !spec_unit<true, S, RAW>(rs, full_left, kc, kring, q + u * S, st);
+                    if (__builtin_expect(redo, 0)) {
+                        SPEC_COUNT(redo);
+                        for (int ii = 0; ii < SPEC_UNIT; ii++) {
+                            const int r = rice_step(rs, kc, kn - 1 - (i0 + u + ii), i0 + u + ii, &flags, kring);
+                            q[(u + ii) * S] = RAW ? ab_zigzag(r) : r;
+                        }
+                    }
+                }
+                rice_sync(rs);
+                if (sub == 0) sh.ring_next[g] = rs.next;
+#ifdef ALAC_DIAG
+                const long long tB = clock64();
+#endif
+                wg_sync();  // chunk c is ready for the FIR wave
+#ifdef ALAC_DIAG
+                st.bar_cycles += clock64() - tB;
+#endif
+            }
+        }
+#endif
         for (; c < c_stop; c++) {
             const int i0 = c * AB_CHUNK;
             int* q = (sub == 0 && kreal) ? &sh.resq[c & 1][0][g] : &sh.dummy[lane];
