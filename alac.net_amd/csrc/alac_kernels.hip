@@ -548,7 +548,7 @@ __device__ __forceinline__ void ab_fir_wave(const alac_decode_params& p, uint32_
     f.bpaddr = ((lane & 48) + 2 * (stream_on ? (m.N - 1) & 7 : 0) + par) * 4;
     const int nmax = __builtin_amdgcn_readfirstlane(wave_max(n_row));
     const int* qzero = &sh.zeros[0][g];
-    for (int c = 0; c < nchunks; c++) {
+    auto chunk = [&](int c) {
         const int i0 = c * AB_CHUNK;
         const unsigned long long tb = p.dbg ? clock64() : 0;
         wg_sync();  // wait for chunk c
@@ -571,7 +571,7 @@ __device__ __forceinline__ void ab_fir_wave(const alac_decode_params& p, uint32_
                 }
                 sh.outq[c & 1][half][64 * w + lane] = f.hist;
             }
-            continue;
+            return;
         }
 #endif
 #pragma unroll
@@ -600,7 +600,37 @@ __device__ __forceinline__ void ab_fir_wave(const alac_decode_params& p, uint32_
             }
             sh.outq[c & 1][half][64 * w + lane] = f.hist;
         }
+    };
+    // The chunks that lie wholly inside every switched-on stream, behind the warm-up chunk, in a loop of their own: one block of 32
+    // steps per barrier, nothing to ask the wave (see ab_entropy_pass; a lone wave pays for every block boundary).
+    int c = 0;
+#if !defined(ALAC_EXPERIMENT) && ALAC_FIR_WHOLE_CHUNK
+    {
+        const int nmin_on = __builtin_amdgcn_readfirstlane(-wave_max(stream_on ? -n_row : (int)0x80000001));
+        const int c_fast = nmax > 0 ? min(nchunks, nmin_on / AB_CHUNK) : 0;
+        const int* const qa = stream_on ? &sh.resq[0][0][g] : qzero;
+        const int qodd = stream_on ? AB_CHUNK * S : 0;
+        if (c_fast > 1) {
+            chunk(0);
+            for (c = 1; c < c_fast; c++) {
+                wg_sync();  // wait for chunk c
+                const int* q = qa + (c & 1) * qodd;
+#pragma unroll
+                for (int half = 0; half < AB_CHUNK / 8; half++) {
+                    int err = q[(8 * half) * S];
+#pragma unroll
+                    for (int ii = 0; ii < 8; ii++) {
+                        const int en = q[(8 * half + (ii < 7 ? ii + 1 : ii)) * S];
+                        fir8_step<false, true>(f, err, c * AB_CHUNK + 8 * half + ii, true);
+                        err = en;
+                    }
+                    sh.outq[c & 1][half][64 * w + lane] = f.hist;
+                }
+            }
+        }
     }
+#endif
+    for (; c < nchunks; c++) chunk(c);
     wg_sync();  // final barrier of the pass
 }
 
