@@ -48,7 +48,7 @@ if "_diag" in os.path.basename(os.environ.get("ALACGPU_LIB", "")):
     f16 = lambda x, sh: ((x >> np.uint64(sh)) & np.uint64(0xFFFF)).astype(np.float64)
     cols = {"plain_ok": hi(s[:, 1]), "fail_esc": lo(s[:, 1]), "z_units": hi(s[:, 4]), "esc_units": lo(s[:, 4]),
             "fail_run": f16(s[:, 5], 48), "redo": f16(s[:, 5], 32), "full_units": f16(s[:, 6], 48), "late_run": f16(s[:, 6], 32),
-            "fir_barrier_wait": s[:, 7].astype(np.float64),
+            "fir_barrier_wait": s[:, 7].astype(np.float64),   # (first and last chunks of a pass only: the FIR wave's common chunks carry no stamps)
             # cycle accounts of the entropy wave (both passes): inside the 8 steps of plain units, at chunk barriers, pass set-up,
             # chunks decoded by the generic step; what is left of `duration` is the code between units and the stamps themselves
             "cyc_plain_steps": lo(s[:, 3]), "cyc_barrier_wait": hi(s[:, 3]), "cyc_pass_setup": lo(s[:, 6]), "cyc_generic_chunks": lo(s[:, 5])}
