@@ -476,314 +476,211 @@ __device__ __forceinline__ void rice_init(Rice& s, uint32_t& filled, uint32_t st
     s.cur = rice_cursor(31 - (int)(p & 31u), s.ra);
 }
 
-// ---- FIR state: tap j = l + 16*t lives in lane l, register t ---------------------------------------
-template <int TPL>
-struct Fir {
-    int hist[TPL];  // out[i-1-j]
-    int coef[TPL];  // predictorCoefTable[j] (0 for j >= N)
-    int base;       // out[i-1-N]            (row-uniform)
-    int prev;       // out[i-1]              (row-uniform)
+// ---- adaptive FIR (PredictorDecompressFirAdapt, AlacFile.cs:256-336): the "blocked" layout --------------------------
+// 8 lanes per stream for EVERY order: in a row of 16 lanes the two parities hold the same channel of two different packets
+// (lane = 2 jl + par), so one wave serves 8 streams; lane jl of a stream holds the T consecutive taps T jl .. T jl + T - 1 in
+// T registers (T = 1: orders up to 8, T = 2: up to 16, T = 4: up to 32).  tap t = history value out[i-1-t], coefficient t.
+//   * dot product: T multiply-adds inside the lane, then three DPP stages (quad_perm[2,3,0,1], row_ror:4, row_ror:8);
+//   * sign-LMS early exit (:312-332; taps are visited from N-1 down to 0 while the running error keeps its sign): with
+//     E = |err| and c_t = the magnitude tap t takes off it, tap t is visited iff E > sum of c_t' over t' > t -- a suffix sum:
+//     T - 1 adds inside the lane, ONE three-stage DPP scan of the lane totals (row_shl:2/4/8, zero fill), T adds back;
+//   * the history moves one tap per sample: inside a lane that is a renaming of registers (the unrolled steps rotate which
+//     physical register plays tap T jl + r; PH = step number mod T), between lanes one row_shr:2 on the register that held
+//     the lane's last tap, which lanes 0 / 1 of the row fill with the new sample;
+//   * history values are kept BIASED by B = 2^(rss-1) (out_u = out + B, in [0, 2^rss) for every truncated sample): the
+//     difference of two values is unchanged, the sign extension (:309-310) becomes one v_bfe_u32 of a sum that carries the
+//     bias in through the base, and |hist - base| + rounding term is ONE v_sad_u32 (three instructions on signed values).
+//     Only a first sample (:260, copied untruncated) or an order-0 stream can hold a value outside [0, 2^rss); the fast
+//     step therefore runs from the second chunk on, when the first sample has left every window (N <= 30 < 32), and
+//     order-0 streams have no taps (weight 0).  The masked step below works on signed differences and has no such condition.
+// What a step needs from the residual arrives pre-digested (XQ; the output wave converts the entropy wave's code values
+// between two barriers): the FIR wave is the one the common workgroup waits for, and every instruction of its step is
+// issued once per sample for 8 streams.
+struct XQ {          // one residual, as the FIR step wants it (16 bytes, one ds_read_b128)
+    int err;         // the residual                                        (AlacFile.cs:225-226)
+    int rq;          // err < 0 ? (1 << q) - 1 : 0    ((-a) >> q == -((a + 2^q - 1) >> q))
+    uint32_t mag;    // |err|
+    int sgn;         // err < 0 ? -1 : +1
 };
-
-template <int TPL>
-__device__ __forceinline__ int fir_step(Fir<TPL>& f, int err, int i, int N, int q, int rnd, int rss, int l,
-                                        int rowlane0) {
-    int out;
-    if (i == 0 || N == 0) {
-        out = err;                                            // :260-267, first sample copies
-    } else if (i <= N || N == 31) {
-        out = __builtin_amdgcn_sbfe(wadd(f.prev, err), 0, rss);  // :268-293
-    } else {
-        int acc = 0;
-        int d[TPL];
-#pragma unroll
-        for (int t = 0; t < TPL; t++) {
-            d[t] = wsub(f.hist[t], f.base);                   // :303
-            acc = wadd(acc, wmul(d[t], f.coef[t]));
-        }
-        int sum = row_allreduce_add(acc);
-        int pred = wadd(wadd(rnd, sum) >> q, f.base);         // :306-308
-        out = __builtin_amdgcn_sbfe(wadd(pred, err), 0, rss);  // :309-310
-        if (err != 0) {                                       // :312-332 sign-LMS, parallel form
-            // tap p is visited in order p = N-1 .. 0 while the running error keeps its sign; with
-            // E = |err| and c_p = the magnitude tap p takes off it, tap p is visited iff
-            // E - sum_{p' > p} c_p' > 0.
-            const int sg = err > 0 ? 1 : -1;
-            const uint32_t E = (uint32_t)(err > 0 ? err : -err);
-            const int rnde = err < 0 ? (1 << q) - 1 : 0;      // (-a) >> q == -((a + 2^q - 1) >> q)
-            uint32_t c[TPL];
-#pragma unroll
-            for (int t = 0; t < TPL; t++) {
-                int a = d[t] < 0 ? -d[t] : d[t];
-                int j = l + 16 * t;
-                uint32_t w = j < N ? (uint32_t)(N - j) : 0u;
-                uint32_t cc = ((uint32_t)(a + rnde) >> q) * w;
-                c[t] = cc < (1u << 26) ? cc : (1u << 26);     // clamp: keeps the scan from wrapping, decisions unchanged
-            }
-            uint32_t upper = 0;  // contribution of the taps in higher registers (visited first)
-#pragma unroll
-            for (int t = TPL - 1; t >= 0; t--) {
-                uint32_t incl = (uint32_t)row_suffix_scan((int)c[t]);
-                uint32_t excl = incl - c[t] + upper;
-                int j = l + 16 * t;
-                bool visit = (j < N) && (E > excl);
-                int sd = d[t] > 0 ? 1 : (d[t] < 0 ? -1 : 0);
-                f.coef[t] += visit ? sg * sd : 0;             // coef[p] -= sign, sign = +-sgn(base - hist) (:325-327)
-                if (t > 0) upper += (uint32_t)row_allreduce_add((int)c[t]);
-            }
-        }
-    }
-    // slide the history: tap N-1 becomes the next base, out enters at tap 0
-    if (N >= 1 && N <= 30) {
-        int src = (TPL > 1 && N > 16) ? f.hist[TPL - 1] : f.hist[0];
-        f.base = __shfl(src, rowlane0 + ((N - 1) & 15), 64);
-    }
-#pragma unroll
-    for (int t = TPL - 1; t >= 1; t--) {
-        int carry = __builtin_amdgcn_update_dpp(0, f.hist[t - 1], DPP_ROW_ROR1, 0xF, 0xF, false);
-        f.hist[t] = __builtin_amdgcn_update_dpp(carry, f.hist[t], DPP_ROW_SHR1, 0xF, 0xF, false);
-    }
-    f.hist[0] = __builtin_amdgcn_update_dpp(out, f.hist[0], DPP_ROW_SHR1, 0xF, 0xF, false);
-    f.prev = out;
-    return out;
-}
-
-// ---- DPP row reductions with a compile-time depth (NRED 3: taps in lanes 0..7 only) ------------------
-template <int NRED>
-__device__ __forceinline__ int row_allreduce_n(int v) {
-    v = wadd(v, dpp0<DPP_QUAD_1032>(v));
-    v = wadd(v, dpp0<DPP_QUAD_2301>(v));
-    v = wadd(v, dpp0<DPP_ROW_HALF_MIRROR>(v));
-    if (NRED > 3) v = wadd(v, dpp0<DPP_ROW_MIRROR>(v));
-    return v;
-}
-template <int NRED>
-__device__ __forceinline__ int row_suffix_scan_n(int v) {
-    v = wadd(v, dpp0<DPP_ROW_SHL1>(v));
-    v = wadd(v, dpp0<DPP_ROW_SHL2>(v));
-    v = wadd(v, dpp0<DPP_ROW_SHL4>(v));
-    if (NRED > 3) v = wadd(v, dpp0<DPP_ROW_SHL8>(v));
-    return v;
-}
-
-// ---- FIR fast step, 16 lanes per stream, one tap register ------------------------------------------------------
-// The steady state of fir_step for rows with 1 <= N <= 16 (i > N), branch-free: 35 instructions against the 80 of the
-// two-register step below.  Lanes >= N keep coef == 0 and w == 0.  A row that is switched off is fed err = 0 / coef = 0.
-struct FirLane {
-    int hist, coef, base;
-    int q, rnd, rss, qmask;   // row-uniform
-    uint32_t w;               // N - j for tap j < N, else 0
-    int bpaddr;               // ds_bpermute byte address of lane N-1 of this row
-    int tlo, thi;             // -1 / +1 on tap lanes (j < N), 0 / 0 elsewhere: bounds of the sign() median
+struct XQ8 {         // the short form (the dense arrangement's LDS budget: four 16-packet workgroups per CU): the step
+    int err;         // derives rq and the sign itself, three more instructions
+    uint32_t mag;
 };
-__device__ __forceinline__ void fir_fast1(FirLane& f, int err) {
-    const int nb = __builtin_amdgcn_ds_bpermute(f.bpaddr, f.hist);   // tap N-1 = next step's base; needed last
-    const int d = wsub(f.hist, f.base);                                       // :303
-    const int p = wmul(d, f.coef);
-    const int sum = row_allreduce_n<4>(p);
-    const int out = __builtin_amdgcn_sbfe(wadd(wadd(wadd(f.rnd, sum) >> f.q, f.base), err), 0, f.rss);  // :306-310
-    // sign-LMS (:312-332), parallel form -- see fir_step for the derivation
-    const int s = err >> 31;
-    const int a = max(d, -d);
-    const uint32_t aq = (uint32_t)(a + (s & f.qmask)) >> f.q;
-    uint32_t cc = min(aq * f.w, 1u << 26);   // clamp: keeps the scan from wrapping, decisions unchanged
-    const uint32_t incl = (uint32_t)row_suffix_scan_n<4>((int)cc);
-    const uint32_t Ecc = (uint32_t)((err ^ s) - s) + cc;      // |err| + own decrement: visit iff |err| > incl - cc
-    int sd;
-    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(sd) : "v"(d), "v"(f.tlo), "v"(f.thi));
-    f.coef += (Ecc > incl) ? (sd ^ s) - s : 0;
-    f.hist = __builtin_amdgcn_update_dpp(out, f.hist, DPP_ROW_SHR1, 0xF, 0xF, false);
-    f.base = nb;
+__device__ __forceinline__ void xq_from_code(XQ& x, uint32_t dv, int qmask) {
+    const int s = -(int)(dv & 1u);
+    const int hq = (int)(dv >> 1);
+    x.err = hq ^ s;                                   // :225-226
+    x.rq = s & qmask;
+    x.mag = (uint32_t)(hq - s);                       // (dv + 1) >> 1
+    x.sgn = s | 1;
+}
+__device__ __forceinline__ void xq_from_code(XQ8& x, uint32_t dv, int) {
+    const int s = -(int)(dv & 1u);
+    const int hq = (int)(dv >> 1);
+    x.err = hq ^ s;
+    x.mag = (uint32_t)(hq - s);
+}
+__device__ __forceinline__ void xq_zero(XQ& x) { x.err = 0; x.rq = 0; x.mag = 0; x.sgn = 0; }
+__device__ __forceinline__ void xq_zero(XQ8& x) { x.err = 0; x.mag = 0; }
+
+// low 24 bits of a and b, signed, times each other plus c: exact mod 2^32 (one v_mad_i32_i24; a builtin rather than inline
+// assembly, so that the compiler may speculate it: around inline assembly it builds a branch)
+__device__ __forceinline__ int mad_i24(int a, int b, int c) { return wadd(__mul24(a, b), c); }
+__device__ __forceinline__ uint32_t sad_u32(uint32_t a, uint32_t b, uint32_t c) {   // |a - b| + c, unsigned
+    uint32_t r;
+    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ int med3_i32(int a, int b, int c) {
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ int xad_u32(int a, int b, int c) {   // (a ^ b) + c
+    int r;
+    asm("v_xad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
 }
 
-// ---- FIR fast step, two tap registers per lane ------------------------------------------------------
-// Steady state for waves in which some stream has more than 16 taps: tap j = l + 16t in lane l, register t.
-// Rows with N <= 16 simply leave register 1 empty (coef = w = 0).  Rows with N == 31 are in the reference's
-// first-order "delta" mode (AlacFile.cs:268-282): they carry no taps at all (coef = w = 0, sign bounds 0) and take
-// out = sx(prev + err).  Taps are visited from 31 down to 0, so register 1's total decrement comes on top of
-// register 0's suffix sums.
-struct FirLane2 {
-    int hist[2], coef[2], base, prev;
-    int q, rnd, rss, qmask;
-    uint32_t w[2];
-    int tlo[2], thi[2];
-    int bpaddr;
-    bool bphi;     // tap N-1 lives in register 1
-    bool delta;    // N == 31
-};
-
-// DELTA: some row of the wave is in the delta mode (else the three instructions of that select are left out).
-template <bool DELTA>
-__device__ __forceinline__ void fir_fast2(FirLane2& f, int err) {
-    const int nb = __builtin_amdgcn_ds_bpermute(f.bpaddr, f.bphi ? f.hist[1] : f.hist[0]);
-    const int d0 = wsub(f.hist[0], f.base), d1 = wsub(f.hist[1], f.base);
-    const int p = wadd(wmul(d0, f.coef[0]), wmul(d1, f.coef[1]));
-    const int sum = row_allreduce_n<4>(p);
-    const int outg = __builtin_amdgcn_sbfe(wadd(wadd(wadd(f.rnd, sum) >> f.q, f.base), err), 0, f.rss);
-    int out = outg;
-    if (DELTA) {
-        const int outd = __builtin_amdgcn_sbfe(wadd(f.prev, err), 0, f.rss);
-        out = f.delta ? outd : outg;
-    }
-    const int s = err >> 31;
-    const int rq = s & f.qmask;
-    const int a0 = max(d0, -d0), a1 = max(d1, -d1);
-    const uint32_t q0 = (uint32_t)(a0 + rq) >> f.q, q1 = (uint32_t)(a1 + rq) >> f.q;
-    const uint32_t c0 = min(q0 * f.w[0], 1u << 26), c1 = min(q1 * f.w[1], 1u << 26);   // clamp: see fir_step
-    const uint32_t i1 = (uint32_t)row_suffix_scan_n<4>((int)c1);
-    // (register 1's total is also i1 in lane 0 of the row; fetching it with one ds_bpermute instead of this second
-    // reduction saves three issue slots -- cfg5 at 16384 packets -4.5 % -- but puts the cross-lane latency on the
-    // coefficient chain: +2 % at 4096 packets, where this step's chain sets the time.  Measured; not taken.)
-    const uint32_t t1 = (uint32_t)row_allreduce_n<4>((int)c1);
-    const uint32_t i0 = (uint32_t)row_suffix_scan_n<4>((int)c0) + t1;
-    const uint32_t E = (uint32_t)((err ^ s) - s);
-    int sd0, sd1;
-    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(sd0) : "v"(d0), "v"(f.tlo[0]), "v"(f.thi[0]));
-    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(sd1) : "v"(d1), "v"(f.tlo[1]), "v"(f.thi[1]));
-    f.coef[1] += (E + c1 > i1) ? (sd1 ^ s) - s : 0;
-    f.coef[0] += (E + c0 > i0) ? (sd0 ^ s) - s : 0;
-    const int carry = __builtin_amdgcn_update_dpp(0, f.hist[0], DPP_ROW_ROR1, 0xF, 0xF, false);
-    f.hist[1] = __builtin_amdgcn_update_dpp(carry, f.hist[1], DPP_ROW_SHR1, 0xF, 0xF, false);
-    f.hist[0] = __builtin_amdgcn_update_dpp(out, f.hist[0], DPP_ROW_SHR1, 0xF, 0xF, false);
-    f.base = nb;
-    if (DELTA) f.prev = out;
-}
-
-// ---- "P8" layout: 8 lanes per stream, the two channels of a packet interleaved in one row -----------------
-// For streams with 1 <= N <= 8.  Row r = packet r of the wave; lane l of the row: channel = l & 1, tap j = l >> 1.
-// Every DPP pattern below moves data between lanes of equal parity, i.e. inside one stream: the dot product is
-// quad_perm[2,3,0,1] + row_ror:4 + row_ror:8, the suffix scan row_shl:2/4/8 (zero fill), the history shift
-// row_shr:2 (lanes 0/1 take the new output), and the A/B partner of a sample is lane ^ 1.  One wave so serves 8
-// streams = 4 packets instead of 2, which halves the reconstruction instructions per packet.
 constexpr int DPP_ROW_SHL_2 = 0x102, DPP_ROW_SHL_4 = 0x104, DPP_ROW_SHL_8 = 0x108, DPP_ROW_SHR2 = 0x112;
 constexpr int DPP_ROW_ROR4 = 0x124, DPP_ROW_ROR8 = 0x128;
 
-struct Fir8Lane {
-    int hist, coef, base, prev;
-    int q, rnd, rss, qmask;   // per stream
-    int N;
-    uint32_t w;               // N - j for tap j < N, else 0
-    int tlo, thi;             // -1 / +1 on tap lanes, 0 / 0 elsewhere
-    int bpaddr;               // ds_bpermute byte address of the lane holding tap N-1 of this stream
+template <int T>
+struct FirB {
+    int h[T];          // biased history: tap T jl + r (logical register r; see PH in firb_step)
+    int c[T];          // predictorCoefTable[T jl + r] (0 past the stream's order)
+    uint32_t w[T];     // N - t for tap t < N, else 0   (:329)
+    int tlo[T], thi[T];// -1 / +1 on tap lanes, 0 / 0 elsewhere: bounds of the sign() median
+    int base;          // biased out[i-1-N]; delta mode: out[i-1]
+    int prev;          // biased out[i-1]: kept by the masked step only
+    int rnd0;          // 1 << (q-1) in lane jl == 0 of a stream in the general mode, 0 elsewhere: enters the sum once
+    int q, rss, qmask, bias;
+    int N;             // 0 for a stream that is switched off
+    int bpaddr;        // ds_bpermute byte address of the lane that holds tap N-1
+    int bsel;          // ... and its register there, (N-1) % T
+    bool n0, delta;    // order 0 (out = err, :260-267) / order 31 (out = sx(prev + err), :268-282)
 };
 
-// GENERIC = false: steady state (every stream of the wave switched on, i > N).  GENERIC = true: also the first
-// sample / warm-up samples (:284-293) and streams that are switched off or already finished (`active` false).
-// RAWQ: `err` arrives as the unsigned Rice code value dv (rice_spec_step<.., RAW>); the residual, its sign mask and its
-// magnitude come out of dv in four instructions, one more than from the residual itself.
-template <bool GENERIC, bool RAWQ = false>
-__device__ __forceinline__ void fir8_step(Fir8Lane& f, int err, int i, bool active) {
-    int s_raw = 0, mag_raw = 0;
-    if (RAWQ) {
-        s_raw = __builtin_amdgcn_sbfe(err, 0, 1);          // -(dv & 1)
-        const int hq = (int)((uint32_t)err >> 1);
-        mag_raw = hq - s_raw;                              // (dv + 1) >> 1
-        err = hq ^ s_raw;                                  // :225-226
-    }
-    const int nb = __builtin_amdgcn_ds_bpermute(f.bpaddr, f.hist);
-    const int d = wsub(f.hist, f.base);                                       // :303
-    int p = wmul(d, f.coef);
+// All-reduce over the 8 lanes of a stream / inclusive suffix sum over them (lane jl gets the sum over lanes >= jl).
+__device__ __forceinline__ int firb_allreduce(int p) {
     p = wadd(p, dpp0<DPP_QUAD_2301>(p));
     p = wadd(p, __builtin_amdgcn_update_dpp(0, p, DPP_ROW_ROR4, 0xF, 0xF, false));
     p = wadd(p, __builtin_amdgcn_update_dpp(0, p, DPP_ROW_ROR8, 0xF, 0xF, false));
-    asm("" : "+v"(p));   // keep this a one-instruction v_add_u32_dpp: merged with the rounding term into a v_add3 it needs a
-                         // separate v_mov_dpp whose old-value register has to be zeroed first (one more instruction per step)
-    int out = __builtin_amdgcn_sbfe(wadd(wadd(wadd(f.rnd, p) >> f.q, f.base), err), 0, f.rss);  // :306-310
-    bool general = true;
-    if (GENERIC) {
-        general = i > f.N;
-        if (i == 0) out = err;                                                // first sample copies
-        else if (!general) out = __builtin_amdgcn_sbfe(wadd(f.prev, err), 0, f.rss);  // warm-up :284-293
-    }
-    const int s = RAWQ ? s_raw : err >> 31;
-    const int a = max(d, -d);
-    const uint32_t aq = (uint32_t)(a + (s & f.qmask)) >> f.q;
-    uint32_t cc = min(aq * f.w, 1u << 26);   // clamp: keeps the scan from wrapping, decisions unchanged
-    uint32_t incl = cc;
-    incl += (uint32_t)dpp0<DPP_ROW_SHL_2>((int)incl);
-    incl += (uint32_t)dpp0<DPP_ROW_SHL_4>((int)incl);
-    incl += (uint32_t)dpp0<DPP_ROW_SHL_8>((int)incl);
-    const uint32_t Ecc = (uint32_t)(RAWQ ? mag_raw : (err ^ s) - s) + cc;
-    int sd;
-    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(sd) : "v"(d), "v"(f.tlo), "v"(f.thi));
-    const bool visit = (Ecc > incl) && (!GENERIC || (general && active));
-    f.coef += visit ? (sd ^ s) - s : 0;
-    const int shifted = __builtin_amdgcn_update_dpp(out, f.hist, DPP_ROW_SHR2, 0xF, 0xF, false);
-    if (!GENERIC || active) {
-        f.hist = shifted;
-        f.base = nb;
-        f.prev = out;
-    }
+    asm("" : "+v"(p));   // keep the last stage a one-instruction v_add_u32_dpp (merged into a v_add3 it needs a v_mov_dpp first)
+    return p;
+}
+__device__ __forceinline__ uint32_t firb_suffix(uint32_t v) {
+    v += (uint32_t)dpp0<DPP_ROW_SHL_2>((int)v);
+    v += (uint32_t)dpp0<DPP_ROW_SHL_4>((int)v);
+    v += (uint32_t)dpp0<DPP_ROW_SHL_8>((int)v);
+    return v;
 }
 
-// The P8 layout with TWO taps per lane, for streams with 9 <= N <= 16 (and any N >= 1 next to them in the wave): lane
-// j of a stream holds tap j in register 0 and tap j + 8 in register 1.  One wave still serves 8 streams; against two
-// waves in the 16-lanes-per-stream layout (fir_fast) that is 56 instead of 90 instructions per sample step of 8 streams.
-// Taps are visited from N-1 down to 0 (:312-332), so register 1's total decrement comes on top of register 0's suffix sums.
-struct Fir8Lane2 {
-    int hist[2], coef[2], base, prev;
-    int q, rnd, rss, qmask;
-    int N;
-    uint32_t w[2];
-    int tlo[2], thi[2];
-    int bpaddr;     // ds_bpermute byte address of the lane holding tap N-1 of this stream
-    bool bphi;      // ... in register 1
-};
+// Steady state (every stream of the wave switched on and past its warm-up, i > N, no first sample left in a window).
+// WIDE: some stream of the wave has rss > 23 (the 24-bit multiply-add would drop bits of hist - base; the clamp keeps the
+// suffix sums from wrapping).  SPECIAL: some stream is of order 0 or 31.  PH: step number mod T (register rotation).
+template <int T, bool WIDE, bool SPECIAL, int PH, typename E>
+__device__ __forceinline__ void firb_step(FirB<T>& f, const E e) {
+    constexpr bool SHORT = sizeof(E) == sizeof(XQ8);
+    XQ x;
+    if constexpr (SHORT) {
+        x.err = e.err;
+        x.mag = e.mag;
+        const int s = e.err >> 31;
+        x.rq = s & f.qmask;
+        x.sgn = s | 1;
+    } else {
+        x = e;
+    }
+    constexpr int P0 = ((0 - PH) % T + T) % T, PL = ((T - 1 - PH) % T + T) % T;
+    int src = f.h[P0];
+#pragma unroll
+    for (int r = 1; r < T; r++) src = (f.bsel == r) ? f.h[((r - PH) % T + T) % T] : src;
+    const int nb = __builtin_amdgcn_ds_bpermute(f.bpaddr, src);     // tap N-1 = the next step's base; needed last
+    int d[T], sd[T];
+    uint32_t cc[T];
+    int p = 0;
+#pragma unroll
+    for (int r = 0; r < T; r++) {
+        const int hr = f.h[((r - PH) % T + T) % T];
+        d[r] = wsub(hr, f.base);                                              // :303
+        if (!WIDE) p = mad_i24(d[r], f.c[r], r == 0 ? f.rnd0 : p);
+        else p = wadd(wmul(d[r], f.c[r]), r == 0 ? f.rnd0 : p);
+        const uint32_t aq = sad_u32((uint32_t)hr, (uint32_t)f.base, (uint32_t)x.rq) >> f.q;
+        cc[r] = aq * f.w[r];                                                  // what the tap takes off |err| (:329)
+        if (WIDE) cc[r] = min(cc[r], 1u << 26);                               // decisions unchanged: |err| < 2^26
+        sd[r] = med3_i32(d[r], f.tlo[r], f.thi[r]);                           // sign(hist - base) on tap lanes
+    }
+    const int sum = firb_allreduce(p);
+    const int xu = wadd(wadd(sum >> f.q, f.base), x.err);                     // :306-308 (biased through the base)
+    int out = (int)__builtin_amdgcn_ubfe((uint32_t)xu, 0u, (uint32_t)f.rss); // :309-310
+    if (SPECIAL) out = f.n0 ? wadd(x.err, f.bias) : out;                      // order 0 copies (:260-267)
+    bool visit[T];
+    if (T == 1) {
+        visit[0] = x.mag + cc[0] > firb_suffix(cc[0]);
+    } else {
+        uint32_t tot = cc[0];
+#pragma unroll
+        for (int r = 1; r < T; r++) tot += cc[r];
+        uint32_t run = firb_suffix(tot) - tot;                                // the lanes above
+#pragma unroll
+        for (int r = T - 1; r >= 0; r--) { visit[r] = x.mag > run; run += cc[r]; }
+    }
+    // coef -= sign, sign = +-sgn(base - hist) (:325-327): the select sits on the median, the sign rides on the multiply-add
+#pragma unroll
+    for (int r = 0; r < T; r++) f.c[r] = mad_i24(visit[r] ? sd[r] : 0, x.sgn, f.c[r]);
+    f.h[PL] = __builtin_amdgcn_update_dpp(out, f.h[PL], DPP_ROW_SHR2, 0xF, 0xF, false);
+    f.base = (SPECIAL && f.delta) ? out : nb;
+}
 
-template <bool GENERIC, bool RAWQ = false>
-__device__ __forceinline__ void fir8x2_step(Fir8Lane2& f, int err, int i, bool active) {
-    int s_raw = 0, mag_raw = 0;
-    if (RAWQ) {
-        s_raw = __builtin_amdgcn_sbfe(err, 0, 1);
-        const int hq = (int)((uint32_t)err >> 1);
-        mag_raw = hq - s_raw;
-        err = hq ^ s_raw;
+// Every case, on signed differences: the first sample (:260), the warm-up samples (:284-293), orders 0 and 31, streams that
+// are switched off or have ended (`active` false), the chunk in which a stream ends.  Register rotation phase 0 on entry
+// and exit.  `err` is the residual, `sgn` its sign mask (err >> 31).
+template <int T>
+__device__ __forceinline__ void firb_step_masked(FirB<T>& f, int err, int i, bool active) {
+    int src = f.h[0];
+#pragma unroll
+    for (int r = 1; r < T; r++) src = (f.bsel == r) ? f.h[r] : src;
+    const int nb = __builtin_amdgcn_ds_bpermute(f.bpaddr, src);
+    int d[T];
+    int p = f.rnd0;
+#pragma unroll
+    for (int r = 0; r < T; r++) {
+        d[r] = wsub(f.h[r], f.base);
+        p = wadd(p, wmul(d[r], f.c[r]));
     }
-    const int nb = __builtin_amdgcn_ds_bpermute(f.bpaddr, f.bphi ? f.hist[1] : f.hist[0]);
-    const int d0 = wsub(f.hist[0], f.base), d1 = wsub(f.hist[1], f.base);           // :303
-    int p = wadd(wmul(d0, f.coef[0]), wmul(d1, f.coef[1]));
-    p = wadd(p, dpp0<DPP_QUAD_2301>(p));
-    p = wadd(p, __builtin_amdgcn_update_dpp(0, p, DPP_ROW_ROR4, 0xF, 0xF, false));
-    p = wadd(p, __builtin_amdgcn_update_dpp(0, p, DPP_ROW_ROR8, 0xF, 0xF, false));
-    int out = __builtin_amdgcn_sbfe(wadd(wadd(wadd(f.rnd, p) >> f.q, f.base), err), 0, f.rss);  // :306-310
-    bool general = true;
-    if (GENERIC) {
-        general = i > f.N;
-        if (i == 0) out = err;
-        else if (!general) out = __builtin_amdgcn_sbfe(wadd(f.prev, err), 0, f.rss);  // warm-up :284-293
+    const int sum = firb_allreduce(p);
+    const int xu = wadd(wadd(sum >> f.q, f.base), err);
+    const bool general = f.N >= 1 && f.N <= 30 && i > f.N;
+    int out;
+    if (i == 0 || f.n0) out = wadd(err, f.bias);                              // copies (:260-267)
+    else if (!general)   // :268-293 (in the delta mode the base IS the previous sample, also behind steady-state steps, which keep no `prev`)
+        out = (int)__builtin_amdgcn_ubfe((uint32_t)wadd(f.delta ? f.base : f.prev, err), 0u, (uint32_t)f.rss);
+    else out = (int)__builtin_amdgcn_ubfe((uint32_t)xu, 0u, (uint32_t)f.rss);
+    const int s = err >> 31;
+    const uint32_t E = (uint32_t)((err ^ s) - s);
+    uint32_t cc[T];
+    uint32_t tot = 0;
+#pragma unroll
+    for (int r = 0; r < T; r++) {
+        const int a = max(d[r], -d[r]);
+        cc[r] = min(((uint32_t)(a + (s & f.qmask)) >> f.q) * f.w[r], 1u << 26);
+        tot += cc[r];
     }
-    const int s = RAWQ ? s_raw : err >> 31;
-    const int rq = s & f.qmask;
-    const int a0 = max(d0, -d0), a1 = max(d1, -d1);
-    const uint32_t q0 = (uint32_t)(a0 + rq) >> f.q, q1 = (uint32_t)(a1 + rq) >> f.q;
-    const uint32_t c0 = min(q0 * f.w[0], 1u << 26), c1 = min(q1 * f.w[1], 1u << 26);   // clamp: see fir8_step
-    uint32_t i1 = c1;
-    i1 += (uint32_t)dpp0<DPP_ROW_SHL_2>((int)i1);
-    i1 += (uint32_t)dpp0<DPP_ROW_SHL_4>((int)i1);
-    i1 += (uint32_t)dpp0<DPP_ROW_SHL_8>((int)i1);
-    uint32_t t1 = c1;                                   // register 1's total, in every lane of the stream
-    t1 += (uint32_t)dpp0<DPP_QUAD_2301>((int)t1);
-    t1 += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t1, DPP_ROW_ROR4, 0xF, 0xF, false);
-    t1 += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t1, DPP_ROW_ROR8, 0xF, 0xF, false);
-    uint32_t i0 = c0;
-    i0 += (uint32_t)dpp0<DPP_ROW_SHL_2>((int)i0);
-    i0 += (uint32_t)dpp0<DPP_ROW_SHL_4>((int)i0);
-    i0 += (uint32_t)dpp0<DPP_ROW_SHL_8>((int)i0);
-    i0 += t1;
-    const uint32_t E = (uint32_t)(RAWQ ? mag_raw : (err ^ s) - s);
-    int sd0, sd1;
-    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(sd0) : "v"(d0), "v"(f.tlo[0]), "v"(f.thi[0]));
-    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(sd1) : "v"(d1), "v"(f.tlo[1]), "v"(f.thi[1]));
-    const bool live = !GENERIC || (general && active);
-    f.coef[1] += ((E + c1 > i1) && live) ? (sd1 ^ s) - s : 0;
-    f.coef[0] += ((E + c0 > i0) && live) ? (sd0 ^ s) - s : 0;
-    const int carry = __builtin_amdgcn_update_dpp(0, f.hist[0], 0x122 /* row_ror:2 */, 0xF, 0xF, false);
-    const int sh1 = __builtin_amdgcn_update_dpp(carry, f.hist[1], DPP_ROW_SHR2, 0xF, 0xF, false);
-    const int sh0 = __builtin_amdgcn_update_dpp(out, f.hist[0], DPP_ROW_SHR2, 0xF, 0xF, false);
-    if (!GENERIC || active) {
-        f.hist[1] = sh1;
-        f.hist[0] = sh0;
-        f.base = nb;
+    uint32_t run = firb_suffix(tot) - tot;
+    const bool live = general && active;
+#pragma unroll
+    for (int r = T - 1; r >= 0; r--) {
+        const int sdr = med3_i32(d[r], f.tlo[r], f.thi[r]);
+        f.c[r] += (live && E > run) ? (sdr ^ s) - s : 0;
+        run += cc[r];
+    }
+    const int h0 = __builtin_amdgcn_update_dpp(out, f.h[T - 1], DPP_ROW_SHR2, 0xF, 0xF, false);
+    if (active) {
+#pragma unroll
+        for (int r = T - 1; r >= 1; r--) f.h[r] = f.h[r - 1];
+        f.h[0] = h0;
+        f.base = f.delta ? out : nb;
         f.prev = out;
     }
 }

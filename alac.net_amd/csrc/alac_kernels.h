@@ -38,7 +38,9 @@ struct alac_decode_params {
     int32_t* out_samples;       // may be null
     int32_t* status;
     uint32_t out_format;        // 0: one int32 per sample; 1: packed little-endian PCM bytes (FormatSamples fused)
-    unsigned long long* dbg;    // diagnostic builds only: per-workgroup s_memtime stamps (null in normal use)
+#ifdef ALAC_DIAG
+    unsigned long long* dbg;    // diagnostic build (make diag) only: 8 stamps per workgroup, see alac_diag.h
+#endif
     // alac_decode_ab_kernel, then alac_decode_ab32_kernel: flag g covers packets 8g .. 8g+7.  The first writes 0 where it
     // decoded the group and 1 where it did not; the second decodes the groups flagged 1 and writes 2 there.  One array per
     // launch pair in flight (the host keeps a pool, alacgpu_api.hip: launch_slot).
@@ -50,13 +52,14 @@ struct alac_decode_params {
 };
 
 #ifdef __HIPCC__
-// two passes (channel A, then B), 8 packets / 256-thread workgroup (three working waves), LPC orders 1..16
+// two passes (channel A, then B), 8 packets / 256-thread workgroup (three working waves), LPC orders 1..8
 extern "C" __global__ void alac_decode_ab_kernel(alac_decode_params p);
-extern "C" __global__ void alac_decode_ab5_kernel(alac_decode_params p);
-extern "C" __global__ void alac_decode_ab_small_kernel(alac_decode_params p);   // the same with 16-step units (batches up to 4096 packets)   // the same with 96 registers (five workgroups per CU)
-// the same for everything else (LPC orders 17..31, delta mode, order 0): two FIR waves (16-lane layout, 2 tap registers)
+extern "C" __global__ void alac_decode_ab5_kernel(alac_decode_params p);         // the same with 96 registers (five workgroups per CU)
+extern "C" __global__ void alac_decode_ab_small_kernel(alac_decode_params p);   // the same with 16-step units (batches up to 4096 packets)
+// the second launch, for the groups of 8 packets the first one flagged: two taps per lane of the FIR wave (orders 9..16) or
+// four (any order, delta mode, order 0)
 extern "C" __global__ void alac_decode_ab32_kernel(alac_decode_params p);
-// the main kernel with 16 packets / 320-thread workgroup (one entropy wave for 16 streams): big batches
+// the first launch with 16 packets / 256-thread workgroup (one entropy wave for 16 streams, orders 1..16): big batches
 extern "C" __global__ void alac_decode_ab_dense_kernel(alac_decode_params p);
 #endif
 

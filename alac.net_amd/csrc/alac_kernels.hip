@@ -9,15 +9,16 @@
 // One kernel family lives here, the "two-pass" kernels: 8 (or 16) packets per workgroup, channel A decoded
 // for real in pass 0 (its end is where B starts: no Rice-only pre-scan), parked in the packet's own output slot, and
 // un-mixed with B in pass 1; one-channel and uncompressed packets finish in pass 0.  Per workgroup: an entropy wave
-// (bitstream staged in per-stream LDS rings, branch-free speculative Rice units -> LDS residual queue), one or two FIR
-// waves (taps across lanes, DPP reductions and scans) and an output wave (un-mix, shift bytes, coalesced PCM stores, ring
-// refills).  (The round-1 "fused" and "split" families were retired in round 2; see git history and DESIGN.md.)
+// (bitstream staged in per-stream LDS rings, branch-free speculative Rice units -> LDS queue of code values), an output
+// wave (turns the code values into what the FIR step wants, un-mixes, merges shift bytes, stores the PCM coalesced, refills
+// the rings) and one FIR wave per 8 streams (8 lanes per stream, 1 / 2 / 4 taps per lane, DPP reductions and scans).
 // No MFMA: the path is integer/branchy, not a contraction.  No floating point anywhere.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "alac_kernels.h"
 #include "alac_device.h"
+#include "alac_diag.h"
 
 using namespace alacdev;
 
@@ -93,25 +94,6 @@ __device__ __forceinline__ void spec_unpark(Rice& rs, const Rice& snap, bool par
     }
 }
 
-// Diagnostic builds (make diag: -DALAC_DIAG) count what the units of a workgroup's entropy wave did; the counts go to the
-// stamp slots of the diagnostic entry point (tools/stamps.py).  Nothing of this exists in the product build.
-struct SpecStats {
-#ifdef ALAC_DIAG
-    int plain_ok = 0, fail_esc = 0, fail_run = 0, z_units = 0, esc_units = 0, full_units = 0, late_run = 0, redo = 0;
-    // cycle accounts of the entropy wave (s_memtime around the parts; the stamps themselves cost ~100 cycles per unit):
-    long long plain_cycles = 0;   // inside the 8 steps of plain-tier units
-    long long bar_cycles = 0;     // waiting at the chunk barriers
-    long long setup = 0;          // pass entry -> first chunk (header facts, ring fill)
-    long long slow_chunk = 0;     // chunks decoded by the generic step
-    long long t_pass = 0;
-#endif
-};
-#ifdef ALAC_DIAG
-#define SPEC_COUNT(field) (st.field++)
-#else
-#define SPEC_COUNT(field) ((void)0)
-#endif
-
 template <bool WANT_R, int QSTRIDE, bool RAW = false>
 __device__ __forceinline__ bool spec_unit(Rice& rs, int& full_left, const RiceCfg& c, uint32_t ring, int* q, SpecStats& st) {
     const Rice snap = rs;
@@ -124,17 +106,11 @@ __device__ __forceinline__ bool spec_unit(Rice& rs, int& full_left, const RiceCf
     int hmin = 0x7FFFFFFF;
     if (full_left == 0) {
         if (!special) {
-#ifdef ALAC_DIAG
-            const long long tA = clock64();
-#endif
 #pragma unroll
             for (int ii = 0; ii < SPEC_UNIT; ii++) {
                 const int r = rice_spec_step<WANT_R, RAW>(rs, c, ring, xmax, hmin, vmax);
                 if (WANT_R) q[ii * QSTRIDE] = r;
             }
-#ifdef ALAC_DIAG
-            st.plain_cycles += clock64() - tA;
-#endif
             spec_unpark<WANT_R, QSTRIDE>(rs, snap, parked, xmax, hmin, q);
             vmax = parked ? 0u : vmax;
         } else {
@@ -201,21 +177,23 @@ __device__ __forceinline__ bool spec_unit(Rice& rs, int& full_left, const RiceCf
 __device__ __forceinline__ int mirror_i(int v, int src) { return __shfl(v, src, 64); }
 
 // ===================================================================================================================
-// v3 "two-pass" kernels: 8 packets per workgroup, three working waves (entropy, output, FIR; which wave takes which role
-// is decided from the SIMDs they landed on, see ab_kernel_body).
-// Pass 0 decodes channel A of all 8 packets for real (entropy wave -> residual queue -> P8 FIR wave) and the output
-// wave parks the reconstructed samples in the upper half of the packet's own output slot; where pass 0 ends IS where
-// channel B starts, so there is no Rice-only pre-scan any more.  Pass 1 decodes channel B the same way and the output
-// wave un-mixes it with the parked A samples (read back one chunk ahead) and stores the PCM.  Both passes keep every
-// lane of the FIR wave busy (8 streams x 8 taps), which the one-pass layout only manages with both channels at once.
-// One-channel and uncompressed packets finish in pass 0.
-// alac_decode_ab_kernel takes the groups of 8 packets whose streams have LPC order 1..8 (one tap per lane of the FIR
-// wave) and flags the others (alac_decode_params::ab_flags) for alac_decode_ab32_kernel, launched behind it: that one runs
-// this same code with two taps per lane for groups with orders 9..16 (its own object file: that path wants another
-// instruction-scheduler strategy, see the Makefile), and for everything else (any order, delta mode) the variant with two
-// FIR waves in the 16-lanes-per-stream layout with two tap registers.  (The dense arrangement keeps orders 1..16.)
+// The "two-pass" kernels: 8 packets per workgroup (16 in the dense arrangement), three working waves per 8 streams
+// (entropy, output, FIR; which wave takes which role is decided from the SIMDs they landed on, see ab_kernel_body).
+// Pass 0 decodes channel A of all packets for real (entropy wave -> queue of code values -> output wave: pre-digested
+// residuals -> FIR wave -> output wave), and the output wave parks the reconstructed samples in the upper half of the
+// packet's own output slot; where pass 0 ends IS where channel B starts, so there is no Rice-only pre-scan.  Pass 1 decodes
+// channel B the same way and the output wave un-mixes it with the parked A samples (read back one chunk ahead) and stores
+// the PCM.  One-channel and uncompressed packets finish in pass 0.
+// The first launch (alac_decode_ab*_kernel) takes the groups of 8 packets whose streams have LPC order 1..8 (one tap per
+// lane of the FIR wave; the dense arrangement: 1..16) and flags the others (alac_decode_params::ab_flags) for
+// alac_decode_ab32_kernel, launched behind it: the same code with two taps per lane (orders 9..16) or four (any order, the
+// delta mode 31, order 0).
 // Parking place: ints [n, 2n) of the slot (slot_ints >= 2n for two channels).  The final stores of sample i touch
 // at most int 2i+1 (int32 output) or byte 6i+5 (packed), always below the parked samples not yet consumed.
+//
+// Barriers: every wave executes nchunks + 2 per pass.  Between barriers b and b+1 the entropy wave decodes chunk b+1, the
+// output wave converts chunk b (resq[b & 1] -> xq[b & 1]) and stores chunk b-2 (outq[b & 1]), the FIR wave reconstructs
+// chunk b-1 (xq[(b-1) & 1] -> outq[(b-1) & 1]): every queue is written in one interval and read in the next.
 // ===================================================================================================================
 
 // The rings are topped up by the OUTPUT wave (which idles most of the time) instead of the entropy wave (which is the
@@ -228,44 +206,41 @@ __device__ __forceinline__ int mirror_i(int v, int src) { return __shfl(v, src, 
 #endif
 constexpr int AB_CHUNK = ALAC_AB_CHUNK;   // samples per barrier (16 were measured too: the critical wave pays its per-chunk overhead twice as often)
 // NS = streams (packets) per workgroup: 8 (one entropy wave of 8 lanes per stream, one FIR wave, one output wave) or 16 (the
-// "dense" arrangement for big batches: ONE entropy wave serves 16 streams with 4 lanes each -- its instructions, more than half
-// of all the kernel issues, are shared by twice as many packets -- next to two FIR waves and two output waves of 8 streams).
+// "dense" arrangement for big batches: ONE entropy wave serves 16 streams with 4 lanes each -- its instructions are shared
+// by twice as many packets -- next to two FIR waves of 8 streams and one output wave for all 16).
+template <int NS> struct XqSel { typedef XQ type; };
+template <> struct XqSel<16> { typedef XQ8 type; };
 template <int NS>
 struct AbSharedT {
+    typedef typename XqSel<NS>::type Xq;
     uint32_t rings[NS][RING_BYTES / 4];
-    int resq[2][AB_CHUNK][NS];
-    int zeros[AB_CHUNK][NS];   // residuals of a switched-off stream
-    int outq[2][AB_CHUNK / 8][NS * 8];   // FIR wave w -> output wave w (lanes 64 w ..), 8 outputs per stream per 8 samples
-    int dummy[AB_CHUNK * NS + 64];
+    int resq[2][AB_CHUNK][NS];           // entropy wave -> output wave: the unsigned Rice code values dv
+    Xq xq[2][AB_CHUNK][NS + 1];          // output wave -> FIR waves; column NS is never written and stays zero: what a
+                                         // switched-off or finished stream is fed
+    int outq[2][AB_CHUNK / 8][NS * 8];   // FIR wave w -> output wave (lanes 64 w ..), 8 outputs per stream per 8 samples
+    int dummy[AB_CHUNK * NS + 64];       // where the entropy wave's lanes without a stream of their own write
     uint32_t ring_next[NS];    // entropy wave -> output wave: Rice::next of the stream at the last barrier
     uint32_t ring_filled[NS];  // entropy wave -> output wave at the start of a pass: bytes staged by rice_init
     uint32_t ring_on[NS];      // stream switched on in this pass
-    // 32-tap kernel: which stream a FIR row serves in pass 0 / 1 (rows 0..3 = first FIR wave) and the inverse.  The streams
-    // of a pass are sorted by LPC order, so that the four cheapest share a wave -- which then takes the one-register step
-    // whenever their orders allow (35 instead of 80 instructions per sample step of four streams).
-    uint8_t stream_at[2][8], row_of[2][8];
 };
-typedef AbSharedT<8> AbShared;
 
-// One entropy pass over stream `g` of every lane group (S = 8 streams, 8 lanes each): the main pass of entropy_wave.
-// Returns the bit position after the last symbol; *flags collects rice_step's flags.
-// The queue of this kernel carries the unsigned code value dv, not the residual (the FIR wave has the cycles to spare
-// and converts it, fir8_step<.., true>): the inverse of r = (dv >> 1) ^ -(dv & 1) for what rice_step hands back.
+// The inverse of r = (dv >> 1) ^ -(dv & 1) (AlacFile.cs:225-226) for what rice_step hands back: the queue carries dv.
 __device__ __forceinline__ int ab_zigzag(int r) { return (int)(((uint32_t)r << 1) ^ (uint32_t)(r >> 31)); }
 
-#ifndef ALAC_FAST_CHUNK_LOOP
-#define ALAC_FAST_CHUNK_LOOP 1
-#endif
-template <bool RAW, int NS>
+// One entropy pass over stream `g` of every lane group.  Returns the bit position after the last symbol; *flags_out
+// collects rice_step's flags.
+template <int NS>
 __device__ __forceinline__ uint32_t ab_entropy_pass(const alac_decode_params& p, AbSharedT<NS>& sh, const Meta& m, const RiceCfg& rc, int init_hist,
-                                    uint32_t startbit, bool stream_on, int g, int sub, int lane, int nchunks, int* flags_out) {
+                                    uint32_t startbit, bool stream_on, int g, int sub, int lane, int nchunks, int* flags_out
+                                    DIAG_ONLY(, SpecStats& st)) {
     constexpr int S = NS, LPS = 64 / NS;
     const int n_row = stream_on ? m.n : 0;
     int flags = 0;
-    int full_left = 0;
+    // every stream's first value is coded against the initial history (a small k): as a rule an escape code -- the pass
+    // starts on the escape tier instead of failing its first plain unit
+    int full_left = 1;
+#ifndef ALAC_DIAG
     SpecStats st;
-#ifdef ALAC_DIAG
-    st.t_pass = clock64();
 #endif
     Rice rs;
     rs.w0 = rs.w1 = rs.w2 = 0; rs.next = 12; rs.hist = 0; rs.signmod = 0; rs.zrun = 0; rs.nforce = 0;
@@ -312,9 +287,6 @@ __device__ __forceinline__ uint32_t ab_entropy_pass(const alac_decode_params& p,
     int endflags = 0;
     bool ended = false;
     int c = 0;
-#ifdef ALAC_DIAG
-    st.setup = clock64() - st.t_pass;
-#endif
     while (c < nchunks) {
         // ---- between stretches: streams that have ended become shadows of the longest one (rare) ----
         {
@@ -356,7 +328,6 @@ __device__ __forceinline__ uint32_t ab_entropy_pass(const alac_decode_params& p,
         const uint32_t kring = mring & ~(uint32_t)RING_MASK;   // (a no-op: rings are 1 KiB aligned -- but the compiler must see it to fold the address into one v_bitop3)
         const int kn = n_eff, knmin = nmin;
         const bool kreal = real;
-#if ALAC_FAST_CHUNK_LOOP && !defined(ALAC_EXPERIMENT)
         // The chunks that lie wholly inside every stream (all but the last one or two of a stretch) in a loop of their own: nothing
         // to decide per chunk (this wave pays for every block boundary: see the FIR waves).
         {
@@ -368,96 +339,63 @@ __device__ __forceinline__ uint32_t ab_entropy_pass(const alac_decode_params& p,
                 int* q = qa + (c & 1) * qodd;
 #pragma unroll
                 for (int u = 0; u < AB_CHUNK; u += SPEC_UNIT) {
-                    const bool redo = !spec_unit<true, S, RAW>(rs, full_left, kc, kring, q + u * S, st);
+                    const bool redo = !spec_unit<true, S, true>(rs, full_left, kc, kring, q + u * S, st);
                     if (__builtin_expect(redo, 0)) {
                         SPEC_COUNT(redo);
                         for (int ii = 0; ii < SPEC_UNIT; ii++) {
                             const int r = rice_step(rs, kc, kn - 1 - (i0 + u + ii), i0 + u + ii, &flags, kring);
-                            q[(u + ii) * S] = RAW ? ab_zigzag(r) : r;
+                            q[(u + ii) * S] = ab_zigzag(r);
                         }
                     }
                 }
                 rice_sync(rs);
                 if (sub == 0) sh.ring_next[g] = rs.next;
-#ifdef ALAC_DIAG
-                const long long tB = clock64();
-#endif
-                wg_sync();  // chunk c is ready for the FIR wave
-#ifdef ALAC_DIAG
-                st.bar_cycles += clock64() - tB;
-#endif
+                wg_sync();  // chunk c is ready for the output wave
             }
         }
-#endif
         for (; c < c_stop; c++) {
             const int i0 = c * AB_CHUNK;
             int* q = (sub == 0 && kreal) ? &sh.resq[c & 1][0][g] : &sh.dummy[lane];
             if (i0 < nmax) {
                 // (a stream may END with the chunk: the reference reads no run symbol behind a stream's last sample, whatever the
                 // history -- AlacFile.cs:231 -- while the speculative step reports one; such a unit is then decoded by rice_step,
-                // which knows.  The generic loop below costs 570 cycles per sample: 36 k cycles per workgroup for cfg2's last chunks)
+                // which knows.  The generic loop below costs 570 cycles per sample.)
                 const bool fast_chunk = i0 + AB_CHUNK <= knmin;
-#if defined(ALAC_EXPERIMENT) && ALAC_EXPERIMENT == 2
-                if (fast_chunk) {
-                    for (int u = 0; u < AB_CHUNK; u++) q[u * S] = 0;
-                } else
-#endif
                 if (fast_chunk) {
 #pragma unroll
                     for (int u = 0; u < AB_CHUNK; u += SPEC_UNIT) {
-                        const bool redo = !spec_unit<true, S, RAW>(rs, full_left, kc, kring, q + u * S, st);
+                        const bool redo = !spec_unit<true, S, true>(rs, full_left, kc, kring, q + u * S, st);
                         if (redo) {
                             SPEC_COUNT(redo);
                             for (int ii = 0; ii < SPEC_UNIT; ii++) {
                                 const int r = rice_step(rs, kc, kn - 1 - (i0 + u + ii), i0 + u + ii, &flags, kring);
-                                q[(u + ii) * S] = RAW ? ab_zigzag(r) : r;
+                                q[(u + ii) * S] = ab_zigzag(r);
                             }
                         }
                     }
                 } else {      // some stream ends in this chunk (or one sample after it): shadows step with their source
-#ifdef ALAC_DIAG
-                    const long long tS = clock64();
-#endif
                     const int qstride = (sub == 0 && kreal) ? S : 0;
                     for (int ii = 0; ii < AB_CHUNK; ii++) {
                         const int i = i0 + ii;
                         int r = 0;
                         if (i < kn) r = rice_step(rs, kc, kn - 1 - i, i, &flags, kring);
-                        q[ii * qstride] = RAW ? ab_zigzag(r) : r;
+                        q[ii * qstride] = ab_zigzag(r);
                     }
-#ifdef ALAC_DIAG
-                    st.slow_chunk += clock64() - tS;
-#endif
                 }
                 rice_sync(rs);
                 if (sub == 0) sh.ring_next[g] = rs.next;
             }
-#ifdef ALAC_DIAG
-            const long long tB = clock64();
-#endif
-            wg_sync();  // chunk c is ready for the FIR wave
-#ifdef ALAC_DIAG
-            st.bar_cycles += clock64() - tB;
-#endif
+            wg_sync();  // chunk c is ready for the output wave
         }
     }
-    wg_sync();      // final barrier of the pass (every wave executes nchunks + 1 per pass)
-#ifdef ALAC_DIAG
-    if (p.dbg && lane == 0 && NS == 8) {   // slot 1: plain ok | escape failures; 4: z units | escape-tier units; 5: run failures, redone | cycles in generic chunks; 6: full, late run | pass set-up cycles; 3: barrier waits | cycles inside plain units
-        unsigned long long* d = p.dbg + 8 * blockIdx.x;
-        d[1] += ((unsigned long long)st.plain_ok << 32) | (unsigned)st.fail_esc;
-        d[4] += ((unsigned long long)st.z_units << 32) | (unsigned)st.esc_units;
-        d[5] += ((unsigned long long)st.fail_run << 48) | ((unsigned long long)st.redo << 32) | (unsigned long long)(st.slow_chunk & 0xFFFFFFFFll);
-        d[6] += ((unsigned long long)st.full_units << 48) | ((unsigned long long)st.late_run << 32) | (unsigned long long)(st.setup & 0xFFFFFFFFll);
-        d[3] += ((unsigned long long)st.bar_cycles << 32) | (unsigned long long)(st.plain_cycles & 0xFFFFFFFFll);
-    }
-#endif
+    wg_sync();      // the two barriers behind the last chunk (every wave executes nchunks + 2 per pass): the chunk is
+    wg_sync();      // converted, then reconstructed
     rice_sync(rs);
     *flags_out = stream_on ? (ended ? endflags : flags) : 0;
     return ended ? endpos : rice_bitpos(rs);
 }
 
-template <int P, int NS>
+template <int NS>
 __device__ __forceinline__ void ab_entropy_wave(const alac_decode_params& p, uint32_t pkt0, int lane, AbSharedT<NS>& sh, int nch0, int nch1) {
     constexpr int LPS = 64 / NS;
     const int g = lane / LPS, sub = lane % LPS;
@@ -478,19 +416,25 @@ __device__ __forceinline__ void ab_entropy_wave(const alac_decode_params& p, uin
     rc.rss = m.rss;
     int flags_a = 0, flags_b = 0;
     uint32_t end_a = m.ricebit, end_b = m.ricebit;
+    DIAG_ONLY(SpecStats st;)
     // one copy of the pass's code for both channels (two would not fit the instruction cache next to the other waves' code)
     for (int ph = 0; ph < (nch1 > 0 ? 2 : 1); ph++) {
         int fl = 0;
         rc.hist_mult = (ph ? mb.ricemod : m.ricemod) * (cfg.rice_history_mult / 4);
-        const uint32_t end = ab_entropy_pass<P == 8, NS>(p, sh, m, rc, cfg.rice_initial_history, ph ? end_a : m.ricebit,
-                                             compressed && (ph == 0 || m.stereo), g, sub, lane, ph ? nch1 : nch0, &fl);
+        const uint32_t end = ab_entropy_pass<NS>(p, sh, m, rc, cfg.rice_initial_history, ph ? end_a : m.ricebit,
+                                             compressed && (ph == 0 || m.stereo), g, sub, lane, ph ? nch1 : nch0, &fl DIAG_ONLY(, st));
         if (ph == 0) { end_a = end_b = end; flags_a = fl; }
         else { end_b = end; flags_b = fl; }
-#ifndef ALAC_DIAG
-        if (p.dbg && lane == 0 && ph == 0) p.dbg[8 * blockIdx.x + 1] = clock64();
-#endif
     }
-    // ---- status, in the reference's control-flow order (same as the other kernels / the oracle) ----
+    DIAG_ONLY(if (p.dbg && lane == 0) {
+        unsigned long long* d = p.dbg + 8 * blockIdx.x;
+        d[1] = ((unsigned long long)st.plain_ok << 32) | (unsigned)st.fail_esc;
+        d[4] = ((unsigned long long)st.z_units << 32) | (unsigned)st.esc_units;
+        d[5] = ((unsigned long long)st.fail_run << 48) | ((unsigned long long)st.redo << 32);
+        d[6] = ((unsigned long long)st.full_units << 48) | ((unsigned long long)st.late_run << 32);
+        d[2] = clock64();
+    })
+    // ---- status, in the reference's control-flow order (same as the oracle) ----
     if (valid && sub == 0) {
         int st = m.status;
         if (st == 0 && !m.esc) {
@@ -514,131 +458,31 @@ __device__ __forceinline__ void ab_entropy_wave(const alac_decode_params& p, uin
     }
 }
 
-// FIR wave, P8 layout (alac_device.h: fir8_step): 8 lanes per stream, the two parities of a row of 16 lanes hold the SAME
-// channel of two different packets, so one wave serves the 8 streams of a pass.
-// w: which block of 8 streams of the workgroup this wave serves (always 0 when NS == 8).
-#ifndef ALAC_FIR_WHOLE_CHUNK
-#define ALAC_FIR_WHOLE_CHUNK 1
-#endif
-template <int NS>
-__device__ __forceinline__ void ab_fir_wave(const alac_decode_params& p, uint32_t pkt0, int w, int lane, AbSharedT<NS>& sh, int ph, int nchunks) {
-    constexpr int S = NS;
-    const int row = lane >> 4, l = lane & 15, par = l & 1, j = l >> 1;
-    const int g = 8 * w + 2 * row + par;
-    const uint32_t pkt = pkt0 + (uint32_t)g;
-    const bool valid = pkt < p.n_packets;
-    alacgpu_cfg_dev cfg;
-    const Meta m = parse_meta(p, pkt, ph, valid, cfg);
-    const bool stream_on = valid && m.status == 0 && !m.esc && (ph == 0 || m.stereo);
-    const int n_row = stream_on ? m.n : 0;
-    Fir8Lane f;
-    f.hist = 0;
-    f.coef = (stream_on && j < m.N) ? (int)(int16_t)peek_bits(m.base, m.limit, m.coefbit + 16u * j, 16) : 0;
-    f.base = 0;
-    f.prev = 0;
-    f.q = stream_on ? m.q : 1;
-    f.rnd = stream_on ? m.rnd : 0;
-    f.rss = stream_on ? m.rss : 16;
-    f.qmask = (1 << f.q) - 1;
-    f.N = stream_on ? m.N : 0;
-    const bool tap = stream_on && j < m.N;
-    f.tlo = tap ? -1 : 0;
-    f.thi = tap ? 1 : 0;
-    f.w = tap ? (uint32_t)(m.N - j) : 0u;
-    f.bpaddr = ((lane & 48) + 2 * (stream_on ? (m.N - 1) & 7 : 0) + par) * 4;
-    const int nmax = __builtin_amdgcn_readfirstlane(wave_max(n_row));
-    const int* qzero = &sh.zeros[0][g];
-    auto chunk = [&](int c) {
-        const int i0 = c * AB_CHUNK;
-        const unsigned long long tb = p.dbg ? clock64() : 0;
-        wg_sync();  // wait for chunk c
-        if (p.dbg && lane == 0 && c > 0) p.dbg[8 * blockIdx.x + 7] += clock64() - tb;   // diagnostic: time spent in barriers
-        // a stream that has ended runs along on zeros (its outputs are not stored); only the chunk in which a stream
-        // ends, and the warm-up, take the masked steps
-        const int* q = (i0 < n_row) ? &sh.resq[c & 1][0][g] : qzero;
-        const bool clean = __builtin_amdgcn_ballot_w64(i0 < n_row && i0 + AB_CHUNK > n_row) == 0;
-#if !defined(ALAC_EXPERIMENT) && ALAC_FIR_WHOLE_CHUNK
-        if (__builtin_expect(clean && i0 > 8 && i0 + AB_CHUNK <= nmax, 1)) {
-            // the common chunk as ONE straight-line block of 32 steps (this wave, too, pays for every block boundary)
+// The 32 steady-state steps of a chunk as one straight-line block (a lone wave pays for every block boundary); I = step
+// number inside the chunk, I % T = the register rotation phase (0 again at every multiple of 8).
+template <int T, bool WIDE, bool SPECIAL, int NS, int I>
+__device__ __forceinline__ void ab_fir_block(FirB<T>& f, const typename XqSel<NS>::type* q, typename XqSel<NS>::type x, int* oq, bool writer,
+                                             const int (&oidx)[T]) {
+    if constexpr (I < AB_CHUNK) {
+        // the next step's residual is fetched one step ahead (an LDS read takes a good hundred cycles to come back)
+        const typename XqSel<NS>::type xn = q[(I + 1 < AB_CHUNK ? I + 1 : I) * (NS + 1)];
+        firb_step<T, WIDE, SPECIAL, I % T>(f, x);
+        if constexpr ((I & 7) == 7) {
 #pragma unroll
-            for (int half = 0; half < AB_CHUNK / 8; half++) {
-                int err = q[(8 * half) * S];
-#pragma unroll
-                for (int ii = 0; ii < 8; ii++) {
-                    const int en = q[(8 * half + (ii < 7 ? ii + 1 : ii)) * S];
-                    fir8_step<false, true>(f, err, i0 + 8 * half + ii, true);
-                    err = en;
-                }
-                sh.outq[c & 1][half][64 * w + lane] = f.hist;
-            }
-            return;
+            for (int r = 0; r < T; r++)
+                if (T == 1 || writer) oq[(I >> 3) * (NS * 8) + oidx[r]] = f.h[r];
         }
-#endif
-#pragma unroll
-        for (int half = 0; half < AB_CHUNK / 8; half++) {
-            const int ih = i0 + 8 * half;
-#if defined(ALAC_EXPERIMENT) && ALAC_EXPERIMENT == 1
-            if (false) {
-#else
-            if (ih < nmax) {
-#endif
-                if (ih > 8 && clean) {
-                    int err = q[(8 * half) * S];
-#pragma unroll
-                    for (int ii = 0; ii < 8; ii++) {
-                        const int en = q[(8 * half + (ii < 7 ? ii + 1 : ii)) * S];
-                        fir8_step<false, true>(f, err, ih + ii, true);
-                        err = en;
-                    }
-                } else {
-                    for (int ii = 0; ii < 8; ii++) {
-                        const int i = ih + ii;
-                        const int err = q[(8 * half + ii) * S];
-                        fir8_step<true, true>(f, err, i, i < n_row);
-                    }
-                }
-            }
-            sh.outq[c & 1][half][64 * w + lane] = f.hist;
-        }
-    };
-    // The chunks that lie wholly inside every switched-on stream, behind the warm-up chunk, in a loop of their own: one block of 32
-    // steps per barrier, nothing to ask the wave (see ab_entropy_pass; a lone wave pays for every block boundary).
-    int c = 0;
-#if !defined(ALAC_EXPERIMENT) && ALAC_FIR_WHOLE_CHUNK
-    {
-        const int nmin_on = __builtin_amdgcn_readfirstlane(-wave_max(stream_on ? -n_row : (int)0x80000001));
-        const int c_fast = nmax > 0 ? min(nchunks, nmin_on / AB_CHUNK) : 0;
-        const int* const qa = stream_on ? &sh.resq[0][0][g] : qzero;
-        const int qodd = stream_on ? AB_CHUNK * S : 0;
-        if (c_fast > 1) {
-            chunk(0);
-            for (c = 1; c < c_fast; c++) {
-                wg_sync();  // wait for chunk c
-                const int* q = qa + (c & 1) * qodd;
-#pragma unroll
-                for (int half = 0; half < AB_CHUNK / 8; half++) {
-                    int err = q[(8 * half) * S];
-#pragma unroll
-                    for (int ii = 0; ii < 8; ii++) {
-                        const int en = q[(8 * half + (ii < 7 ? ii + 1 : ii)) * S];
-                        fir8_step<false, true>(f, err, c * AB_CHUNK + 8 * half + ii, true);
-                        err = en;
-                    }
-                    sh.outq[c & 1][half][64 * w + lane] = f.hist;
-                }
-            }
-        }
+        ab_fir_block<T, WIDE, SPECIAL, NS, I + 1>(f, q, xn, oq, writer, oidx);
     }
-#endif
-    for (; c < nchunks; c++) chunk(c);
-    wg_sync();  // final barrier of the pass
 }
 
-// The same wave for workgroups in which some stream has 9 <= N <= 16: two taps per lane (fir8x2_step).
-template <int NS>
-__device__ __forceinline__ void ab_fir_wave2(const alac_decode_params& p, uint32_t pkt0, int w, int lane, AbSharedT<NS>& sh, int ph, int nchunks) {
-    constexpr int S = NS;
-    const int row = lane >> 4, l = lane & 15, par = l & 1, j = l >> 1;
+// FIR wave (alac_device.h: the blocked layout): 8 lanes per stream, T taps per lane; the two parities of a row of 16 lanes
+// hold the SAME channel of two different packets, so one wave serves the 8 streams of a pass.
+// w: which block of 8 streams of the workgroup this wave serves (always 0 when NS == 8).
+template <int T, bool WIDE, bool SPECIAL, int NS>
+__device__ __forceinline__ void ab_fir_wave(const alac_decode_params& p, uint32_t pkt0, int w, int lane, AbSharedT<NS>& sh, int ph, int nchunks) {
+    constexpr int QS = NS + 1;
+    const int row = lane >> 4, l = lane & 15, par = l & 1, jl = l >> 1;
     const int g = 8 * w + 2 * row + par;
     const uint32_t pkt = pkt0 + (uint32_t)g;
     const bool valid = pkt < p.n_packets;
@@ -646,173 +490,67 @@ __device__ __forceinline__ void ab_fir_wave2(const alac_decode_params& p, uint32
     const Meta m = parse_meta(p, pkt, ph, valid, cfg);
     const bool stream_on = valid && m.status == 0 && !m.esc && (ph == 0 || m.stereo);
     const int n_row = stream_on ? m.n : 0;
-    Fir8Lane2 f;
-    f.base = 0;
-    f.prev = 0;
+    const bool gen = stream_on && m.N >= 1 && m.N <= 30;     // the general mode (:297-334)
+    FirB<T> f;
     f.q = stream_on ? m.q : 1;
-    f.rnd = stream_on ? m.rnd : 0;
     f.rss = stream_on ? m.rss : 16;
     f.qmask = (1 << f.q) - 1;
+    f.bias = 1 << (f.rss - 1);
     f.N = stream_on ? m.N : 0;
+    f.n0 = stream_on && m.N == 0;
+    f.delta = stream_on && m.N == 31;
+    f.rnd0 = (gen && jl == 0) ? m.rnd : 0;
+    f.base = f.prev = f.bias;
+    int oidx[T];           // where this lane's registers go in the output queue: tap t < 8 -> the lane 2 t + par of the row
 #pragma unroll
-    for (int t = 0; t < 2; t++) {
-        const int tapno = j + 8 * t;
-        const bool tap = stream_on && tapno < m.N;
-        f.hist[t] = 0;
-        f.coef[t] = tap ? (int)(int16_t)peek_bits(m.base, m.limit, m.coefbit + 16u * tapno, 16) : 0;
-        f.tlo[t] = tap ? -1 : 0;
-        f.thi[t] = tap ? 1 : 0;
-        f.w[t] = tap ? (uint32_t)(m.N - tapno) : 0u;
+    for (int r = 0; r < T; r++) {
+        const int t = T * jl + r;
+        const bool tap = gen && t < m.N;
+        f.h[r] = f.bias;
+        f.c[r] = tap ? (int)(int16_t)peek_bits(m.base, m.limit, m.coefbit + 16u * t, 16) : 0;   // :466-475
+        f.tlo[r] = tap ? -1 : 0;
+        f.thi[r] = tap ? 1 : 0;
+        f.w[r] = tap ? (uint32_t)(m.N - t) : 0u;
+        oidx[r] = 64 * w + (lane & 48) + 2 * (t & 7) + par;
     }
-    f.bpaddr = ((lane & 48) + 2 * (stream_on ? (m.N - 1) & 7 : 0) + par) * 4;
-    f.bphi = stream_on && m.N > 8;
+    const bool writer = T * jl < 8;     // this lane holds taps below 8: the newest 8 samples after every 8 steps
+    const int tl = gen ? m.N - 1 : 0;
+    f.bpaddr = ((lane & 48) + 2 * (tl / T) + par) * 4;
+    f.bsel = tl % T;
     const int nmax = __builtin_amdgcn_readfirstlane(wave_max(n_row));
-    const int* qzero = &sh.zeros[0][g];
+    const int nmin_on = __builtin_amdgcn_readfirstlane(-wave_max(stream_on ? -n_row : (int)0x80000001));
+    const int c_fast = nmax > 0 ? min(nchunks, nmin_on / AB_CHUNK) : 0;      // chunks that lie wholly inside every switched-on stream
+    constexpr int QODD = AB_CHUNK * QS;
+    wg_sync();      // barrier 0 of the pass: chunk 0 decoded, not yet converted
     for (int c = 0; c < nchunks; c++) {
+        wg_sync();  // chunk c is converted
         const int i0 = c * AB_CHUNK;
-        wg_sync();  // wait for chunk c
-        const int* q = (i0 < n_row) ? &sh.resq[c & 1][0][g] : qzero;    // see ab_fir_wave
-        const bool clean = __builtin_amdgcn_ballot_w64(i0 < n_row && i0 + AB_CHUNK > n_row) == 0;
-#if ALAC_FIR_WHOLE_CHUNK
-        if (__builtin_expect(clean && i0 > 16 && i0 + AB_CHUNK <= nmax, 1)) {     // see ab_fir_wave
-#pragma unroll
-            for (int half = 0; half < AB_CHUNK / 8; half++) {
-                int err = q[(8 * half) * S];
-#pragma unroll
-                for (int ii = 0; ii < 8; ii++) {
-                    const int en = q[(8 * half + (ii < 7 ? ii + 1 : ii)) * S];
-                    fir8x2_step<false, true>(f, err, i0 + 8 * half + ii, true);
-                    err = en;
-                }
-                sh.outq[c & 1][half][64 * w + lane] = f.hist[0];
-            }
+        int* const oq = &sh.outq[c & 1][0][0];
+        // a stream that is switched off or has ended runs along on zeros (its outputs are not stored)
+        const typename XqSel<NS>::type* const q = &sh.xq[0][0][(i0 < n_row) ? g : NS] + (c & 1) * QODD;
+        // The common chunk -- behind the warm-up chunk and wholly inside every stream that is still running -- is 32 steady-state
+        // steps in one block.  While it lies inside every switched-on stream there is nothing to ask the wave (c < c_fast);
+        // behind the end of the shortest one (ragged batches) it must not be the chunk in which a stream ends.
+        bool fast = c >= 1;
+        if (__builtin_expect(c >= c_fast, 0))
+            fast = fast && i0 + AB_CHUNK <= nmax && __builtin_amdgcn_ballot_w64(i0 < n_row && i0 + AB_CHUNK > n_row) == 0;
+        if (__builtin_expect(fast, 1)) {
+            ab_fir_block<T, WIDE, SPECIAL, NS, 0>(f, q, q[0], oq, writer, oidx);
             continue;
         }
-#endif
-#pragma unroll
+#pragma unroll 1
         for (int half = 0; half < AB_CHUNK / 8; half++) {
             const int ih = i0 + 8 * half;
             if (ih < nmax) {
-                if (ih > 16 && clean) {
-                    int err = q[(8 * half) * S];
-#pragma unroll
-                    for (int ii = 0; ii < 8; ii++) {
-                        const int en = q[(8 * half + (ii < 7 ? ii + 1 : ii)) * S];
-                        fir8x2_step<false, true>(f, err, ih + ii, true);
-                        err = en;
-                    }
-                } else {
-                    for (int ii = 0; ii < 8; ii++) {
-                        const int i = ih + ii;
-                        const int err = q[(8 * half + ii) * S];
-                        fir8x2_step<true, true>(f, err, i, i < n_row);
-                    }
+#pragma unroll 1
+                for (int ii = 0; ii < 8; ii++) {
+                    const int i = ih + ii;
+                    firb_step_masked<T>(f, q[(8 * half + ii) * QS].err, i, i < n_row);
                 }
             }
-            sh.outq[c & 1][half][64 * w + lane] = f.hist[0];
-        }
-    }
-    wg_sync();  // final barrier of the pass
-}
-
-// FIR wave of the 32-tap variant (alac_decode_ab32_kernel): the P16 layout (a row of 16 lanes per stream) with two tap registers per
-// lane (tap j = l + 16 t of a stream in lane l of its row of 16; fir_fast2, which also does the delta mode N == 31), four
-// packets per wave, two such waves per workgroup (w = 0 / 1: packets 0..3 / 4..7).  The queue carries residuals here.
-__device__ __forceinline__ void ab_fir16_wave(const alac_decode_params& p, uint32_t pkt0, int w, int lane, AbShared& sh, int ph, int nchunks) {
-    constexpr int S = 8;
-    const int l = lane & 15, rowlane0 = lane & 48;
-    const int g = sh.stream_at[ph][4 * w + (lane >> 4)];
-    const uint32_t pkt = pkt0 + (uint32_t)g;
-    const bool valid = pkt < p.n_packets;
-    alacgpu_cfg_dev cfg;
-    const Meta m = parse_meta(p, pkt, ph, valid, cfg);
-    const bool stream_on = valid && m.status == 0 && !m.esc && (ph == 0 || m.stereo);
-    const int n_row = stream_on ? m.n : 0;
-    Fir<2> f;
-    FirLane2 f2;
 #pragma unroll
-    for (int t = 0; t < 2; t++) {
-        const int j = l + 16 * t;
-        f.hist[t] = 0;
-        f.coef[t] = (stream_on && j < m.N) ? (int)(int16_t)peek_bits(m.base, m.limit, m.coefbit + 16u * j, 16) : 0;
-        const bool tp = stream_on && m.N != 31 && j < m.N;
-        f2.tlo[t] = tp ? -1 : 0;
-        f2.thi[t] = tp ? 1 : 0;
-        f2.w[t] = tp ? (uint32_t)(m.N - j) : 0u;
-    }
-    f.base = 0;
-    f.prev = 0;
-    f2.q = stream_on ? m.q : 1;
-    f2.rnd = stream_on ? m.rnd : 0;
-    f2.rss = stream_on ? m.rss : 16;
-    f2.qmask = (1 << f2.q) - 1;
-    f2.delta = stream_on && m.N == 31;
-    f2.bphi = stream_on && m.N != 31 && m.N > 16;
-    f2.bpaddr = (rowlane0 + ((stream_on && m.N != 31) ? (m.N - 1) & 15 : 0)) * 4;
-    const int nmax = __builtin_amdgcn_readfirstlane(wave_max(n_row));
-    const int Nw = __builtin_amdgcn_readfirstlane(wave_max((stream_on && m.N != 31) ? m.N : 0));
-    const bool taps_ok = __builtin_amdgcn_ballot_w64(stream_on && m.N < 1) == 0;   // fir_fast2 wants N >= 1 in every row
-    // every stream of this wave has at most 16 taps (and none is in the delta mode): one tap register does
-    const bool any_delta = __builtin_amdgcn_ballot_w64(stream_on && m.N == 31) != 0;
-    const bool one_reg = Nw <= 16 && !any_delta;
-    const int* qzero = &sh.zeros[0][g];
-    for (int c = 0; c < nchunks; c++) {
-        const int i0 = c * AB_CHUNK;
-        wg_sync();  // wait for chunk c
-        const int* q = (i0 < n_row) ? &sh.resq[c & 1][0][g] : qzero;    // see ab_fir_wave
-        const bool clean = __builtin_amdgcn_ballot_w64(i0 < n_row && i0 + AB_CHUNK > n_row) == 0;
-#pragma unroll
-        for (int blk = 0; blk < AB_CHUNK / 16; blk++) {
-            const int ih = i0 + 16 * blk;
-            if (ih < nmax) {
-                if (ih > Nw && ih > 0 && clean && taps_ok && one_reg) {
-                    FirLane f1;
-                    f1.hist = f.hist[0]; f1.coef = f.coef[0]; f1.base = f.base;
-                    f1.q = f2.q; f1.rnd = f2.rnd; f1.rss = f2.rss; f1.qmask = f2.qmask;
-                    f1.w = f2.w[0]; f1.bpaddr = f2.bpaddr; f1.tlo = f2.tlo[0]; f1.thi = f2.thi[0];
-                    int err = q[(16 * blk) * S];
-#pragma unroll
-                    for (int ii = 0; ii < 16; ii++) {
-                        const int en = q[(16 * blk + (ii < 15 ? ii + 1 : ii)) * S];
-                        fir_fast1(f1, err);
-                        err = en;
-                    }
-                    f.hist[0] = f1.hist; f.coef[0] = f1.coef; f.base = f1.base;
-                    f.prev = __shfl(f1.hist, rowlane0, 64);     // out[i-1] = tap 0 (only the masked steps look at it)
-                } else if (ih > Nw && ih > 0 && clean && taps_ok) {
-                    f2.hist[0] = f.hist[0]; f2.hist[1] = f.hist[1];
-                    f2.coef[0] = f.coef[0]; f2.coef[1] = f.coef[1];
-                    f2.base = f.base;
-                    f2.prev = f.prev;
-                    int err = q[(16 * blk) * S];
-                    if (__builtin_expect(!any_delta, 1)) {
-#pragma unroll
-                        for (int ii = 0; ii < 16; ii++) {
-                            const int en = q[(16 * blk + (ii < 15 ? ii + 1 : ii)) * S];
-                            fir_fast2<false>(f2, err);
-                            err = en;
-                        }
-                        f2.prev = __shfl(f2.hist[0], rowlane0, 64);   // out[i-1] = tap 0 (only the masked steps look at it)
-                    } else {
-#pragma unroll
-                        for (int ii = 0; ii < 16; ii++) {
-                            const int en = q[(16 * blk + (ii < 15 ? ii + 1 : ii)) * S];
-                            fir_fast2<true>(f2, err);
-                            err = en;
-                        }
-                    }
-                    f.hist[0] = f2.hist[0]; f.hist[1] = f2.hist[1];
-                    f.coef[0] = f2.coef[0]; f.coef[1] = f2.coef[1];
-                    f.base = f2.base;
-                    f.prev = f2.prev;
-                } else {
-                    for (int ii = 0; ii < 16; ii++) {
-                        const int i = ih + ii;
-                        if (i < n_row) (void)fir_step<2>(f, q[(16 * blk + ii) * S], i, m.N, m.q, m.rnd, m.rss, l, rowlane0);
-                    }
-                }
-            }
-            sh.outq[c & 1][2 * blk + w][lane] = f.hist[0];   // lane l of a row holds out[last - l] of its stream
+            for (int r = 0; r < T; r++)
+                if (T == 1 || writer) oq[half * (NS * 8) + oidx[r]] = f.h[r];
         }
     }
     wg_sync();  // final barrier of the pass
@@ -890,164 +628,187 @@ struct AbRefill {
     }
 };
 
-// Lane -> (stream g, sample j of a block of 8): P == 8 reads the FIR wave's P8 layout lane for lane; P == 16 lets lane
-// group g = lane >> 3 pick its stream's 16 outputs per block of 16 out of the two FIR waves' P16 layouts, 8 and 8.
-template <int P, int NS>
-__device__ __forceinline__ int ab_outq_read(const AbSharedT<NS>& sh, int c, int half, int w, int lane, int g, int j, int ph) {
-    if (P == 8) return sh.outq[c & 1][half][64 * w + lane];   // lane (2t + par) holds out[last - t] of its stream
-    const int r = sh.row_of[ph][g];                           // the FIR row that serves stream g in this pass
-    return sh.outq[c & 1][(half & ~1) + (r >> 2)][((r & 3) << 4) + j + 8 * (half & 1)];
-}
-
 // The output work for one block of 8 streams (block w of the workgroup): what happens between two chunk barriers of pass 0
 // (pass0_step) and of pass 1 (pass1_step).  One output wave serves one block (8-packet workgroups) or both blocks of a
 // 16-packet workgroup, one after the other, between the same two barriers.
-template <int P, int NS>
+// Two lane -> stream mappings live here: the FIR wave's (lane 2 j + par of a row holds out[last - j] of stream 2 row + par),
+// for the queue of reconstructed samples, and a linear one (stream lane & 7, sample lane >> 3) for the conversion of the code
+// values and for the ring refill.
+template <int NS>
 struct AbOutBlock {
     const alac_decode_params& p;
     AbSharedT<NS>& sh;
     int w, lane, j, g;
     Meta m;
-    int n_out;
+    int n_out, bias;
     bool two_pass;
     int32_t* pcm_slot;
     int32_t* park;
     AbRefill<NS> rf;
     int a_next[AB_CHUNK / 8];
+    int cs, cq[2];          // conversion: this lane's stream and the quantiser masks (1 << q) - 1 of its two channels
     __device__ AbOutBlock(const alac_decode_params& p_, uint32_t pkt0, int w_, int lane_, AbSharedT<NS>& sh_)
         : p(p_), sh(sh_), w(w_), lane(lane_), rf(p_, pkt0, w_, lane_, sh_) {
         const int row = lane >> 4, l = lane & 15, par = l & 1;
-        j = P == 8 ? l >> 1 : lane & 7;
-        g = P == 8 ? 8 * w + 2 * row + par : lane >> 3;
+        j = l >> 1;
+        g = 8 * w + 2 * row + par;
         const uint32_t pkt = pkt0 + (uint32_t)g;
         const bool valid = pkt < p.n_packets;
         alacgpu_cfg_dev cfg;
         m = parse_meta(p, pkt, 0, valid, cfg);
         n_out = (valid && m.status == 0) ? m.n : 0;
+        bias = 1 << (m.rss - 1);
         two_pass = n_out > 0 && m.stereo && !m.esc;   // A is parked in pass 0 and finished in pass 1
         pcm_slot = p.pcm_out + (int64_t)pkt * p.slot_ints;
         park = pcm_slot + m.n;
 #pragma unroll
         for (int h = 0; h < AB_CHUNK / 8; h++) a_next[h] = 0;
+        cs = 8 * w + (lane & 7);
+        const uint32_t cpkt = pkt0 + (uint32_t)cs;
+        const bool cvalid = cpkt < p.n_packets;
+        const Meta ca = parse_meta(p, cpkt, 0, cvalid, cfg);
+        const Meta cb = parse_meta(p, cpkt, 1, cvalid, cfg);
+        cq[0] = (1 << ca.q) - 1;
+        cq[1] = (1 << cb.q) - 1;
     }
-    // after barrier c of pass 0: chunk c-1's outputs are in the queue
-    __device__ __forceinline__ void pass0_step(int c, int nch0) {
-        if (c < nch0) rf.issue(c == 0);
-        if (c == 0) { rf.commit(); return; }
+    // after barrier b of a pass: chunk b's code values -> what the FIR step wants (four residuals per lane)
+    __device__ __forceinline__ void convert(int b, int ph) {
+        const int (*src)[NS] = sh.resq[b & 1];
+        typename XqSel<NS>::type (*dst)[NS + 1] = sh.xq[b & 1];
 #pragma unroll
-        for (int half = 0; half < AB_CHUNK / 8; half++) {
-            const int ih = (c - 1) * AB_CHUNK + (P == 8 ? 8 * half : 16 * (half >> 1));   // start of the FIR layout's block
-            const int jb = P == 8 ? j : j + 8 * (half & 1);                                   // position in that block
-            const int cnt = min(P, n_out - ih);
-            if (jb >= cnt) continue;
-            const int mine = ab_outq_read<P, NS>(sh, c - 1, half, w, lane, g, j, 0);
-            if (m.esc) {                                            // uncompressed: raw samples, both channels now
-                const int i = ih + jb;
-                const int nch = m.stereo ? 2 : 1;
-                for (int ch = 0; ch < nch; ch++) {
-                    const uint32_t bp = m.rawbit + (uint32_t)((i * nch + ch) * m.ss);
-                    int val = __builtin_amdgcn_sbfe((int)peek_bits(m.base, m.limit, bp, m.ss), 0, m.ss);
-                    if (m.ss == 24) val = __builtin_amdgcn_sbfe(val, 0, 24);
-                    if (ch < m.nc) store_sample(p, m, pcm_slot, (int64_t)i * m.nc + ch, val);
-                }
-                if (!m.stereo && m.nc > 1) store_sample(p, m, pcm_slot, (int64_t)i * m.nc + 1, 0);
-            } else {
-                const int i = ih + cnt - 1 - jb;
-                if (two_pass) {
-                    park[i] = mine;
-                } else {                                            // one channel: done
-                    store_sample(p, m, pcm_slot, (int64_t)i * m.nc, ab_finish24(m, mine, i, 0));
-                    if (m.nc > 1) store_sample(p, m, pcm_slot, (int64_t)i * m.nc + 1, 0);
+        for (int k = 0; k < AB_CHUNK / 8; k++) {
+            const int i = (lane >> 3) + 8 * k;
+            typename XqSel<NS>::type x;
+            xq_from_code(x, (uint32_t)src[i][cs], cq[ph]);
+            dst[i][cs] = x;
+        }
+    }
+    // after barrier b of pass 0: chunk b-2's outputs are in the queue
+    __device__ __forceinline__ void pass0_step(int b, int nch0) {
+        if (b < nch0) { rf.issue(b == 0); convert(b, 0); }
+        if (b >= 2) {
+            const int c = b - 2;
+#pragma unroll
+            for (int half = 0; half < AB_CHUNK / 8; half++) {
+                const int ih = c * AB_CHUNK + 8 * half;                    // start of the FIR layout's block
+                const int cnt = min(8, n_out - ih);
+                if (j >= cnt) continue;
+                const int mine = sh.outq[c & 1][half][64 * w + lane] - bias;   // lane (2 t + par) holds out[last - t] of its stream
+                if (m.esc) {                                            // uncompressed: raw samples, both channels now
+                    const int i = ih + j;
+                    const int nch = m.stereo ? 2 : 1;
+                    for (int ch = 0; ch < nch; ch++) {
+                        const uint32_t bp = m.rawbit + (uint32_t)((i * nch + ch) * m.ss);
+                        int val = __builtin_amdgcn_sbfe((int)peek_bits(m.base, m.limit, bp, m.ss), 0, m.ss);
+                        if (m.ss == 24) val = __builtin_amdgcn_sbfe(val, 0, 24);
+                        if (ch < m.nc) store_sample(p, m, pcm_slot, (int64_t)i * m.nc + ch, val);
+                    }
+                    if (!m.stereo && m.nc > 1) store_sample(p, m, pcm_slot, (int64_t)i * m.nc + 1, 0);
+                } else {
+                    const int i = ih + cnt - 1 - j;
+                    if (two_pass) {
+                        park[i] = mine;
+                    } else {                                            // one channel: done
+                        store_sample(p, m, pcm_slot, (int64_t)i * m.nc, ab_finish24(m, mine, i, 0));
+                        if (m.nc > 1) store_sample(p, m, pcm_slot, (int64_t)i * m.nc + 1, 0);
+                    }
                 }
             }
         }
-        if (c < nch0) rf.commit();
+        if (b < nch0) rf.commit();
     }
-    // after barrier c of pass 1: B arrives, A comes back from its parking place (loaded one chunk ahead)
-    __device__ __forceinline__ void pass1_step(int c, int nch1) {
-        if (c < nch1) rf.issue(c == 0);
+    // after barrier b of pass 1: B's chunk b-2 arrives, A comes back from its parking place (loaded one step ahead)
+    __device__ __forceinline__ void pass1_step(int b, int nch1) {
+        if (b < nch1) { rf.issue(b == 0); convert(b, 1); }
         int a_cur[AB_CHUNK / 8];
 #pragma unroll
         for (int h = 0; h < AB_CHUNK / 8; h++) a_cur[h] = a_next[h];
 #pragma unroll
-        for (int half = 0; half < AB_CHUNK / 8; half++) {                      // A for chunk c (used after the next barrier)
-            const int ih = c * AB_CHUNK + (P == 8 ? 8 * half : 16 * (half >> 1));
-            const int jb = P == 8 ? j : j + 8 * (half & 1);
-            const int cnt = min(P, n_out - ih);
-            a_next[half] = (two_pass && c < nch1 && jb < cnt) ? park[ih + cnt - 1 - jb] : 0;
+        for (int half = 0; half < AB_CHUNK / 8; half++) {                      // A for chunk b-1 (used after the next barrier)
+            const int ih = (b - 1) * AB_CHUNK + 8 * half;
+            const int cnt = min(8, n_out - ih);
+            a_next[half] = (two_pass && b >= 1 && b <= nch1 && j < cnt) ? park[ih + cnt - 1 - j] : 0;
         }
-        if (c == 0) { rf.commit(); return; }
+        if (b >= 2) {
+            const int c = b - 2;
 #pragma unroll
-        for (int half = 0; half < AB_CHUNK / 8; half++) {
-            const int ih = (c - 1) * AB_CHUNK + (P == 8 ? 8 * half : 16 * (half >> 1));
-            const int jb = P == 8 ? j : j + 8 * (half & 1);
-            const int cnt = min(P, n_out - ih);
-            if (!two_pass || jb >= cnt) continue;
-            const int i = ih + cnt - 1 - jb;
-            const int a = a_cur[half], b = ab_outq_read<P, NS>(sh, c - 1, half, w, lane, g, j, 1);
-            int left, right;
-            if (m.mixweight != 0) {                                 // AlacFile.cs:346-357 / :377-388
-                right = wsub(a, wmul(b, m.mixweight) >> (m.mixshift & 31));
-                left = wadd(right, b);
-            } else {
-                left = a;
-                right = b;
+            for (int half = 0; half < AB_CHUNK / 8; half++) {
+                const int ih = c * AB_CHUNK + 8 * half;
+                const int cnt = min(8, n_out - ih);
+                if (!two_pass || j >= cnt) continue;
+                const int i = ih + cnt - 1 - j;
+                const int a = a_cur[half], bb = sh.outq[c & 1][half][64 * w + lane] - bias;
+                int left, right;
+                if (m.mixweight != 0) {                                 // AlacFile.cs:346-357 / :377-388
+                    right = wsub(a, wmul(bb, m.mixweight) >> (m.mixshift & 31));
+                    left = wadd(right, bb);
+                } else {
+                    left = a;
+                    right = bb;
+                }
+                store_sample(p, m, pcm_slot, (int64_t)i * m.nc, ab_finish24(m, left, i, 0));
+                if (m.nc > 1) store_sample(p, m, pcm_slot, (int64_t)i * m.nc + 1, ab_finish24(m, right, i, 1));
             }
-            store_sample(p, m, pcm_slot, (int64_t)i * m.nc, ab_finish24(m, left, i, 0));
-            if (m.nc > 1) store_sample(p, m, pcm_slot, (int64_t)i * m.nc + 1, ab_finish24(m, right, i, 1));
         }
-        if (c < nch1) rf.commit();
+        if (b < nch1) rf.commit();
     }
 };
 
-template <int P, int NS>
+template <int NS>
 __device__ __forceinline__ void ab_output_wave(const alac_decode_params& p, uint32_t pkt0, int lane, AbSharedT<NS>& sh, int nch0, int nch1) {
-    AbOutBlock<P, NS> b0(p, pkt0, 0, lane, sh);
+    AbOutBlock<NS> b0(p, pkt0, 0, lane, sh);
     if constexpr (NS == 16) {
-        AbOutBlock<P, NS> b1(p, pkt0, 1, lane, sh);
-        for (int c = 0; c <= nch0; c++) {
+        AbOutBlock<NS> b1(p, pkt0, 1, lane, sh);
+        for (int b = 0; b <= nch0 + 1; b++) {
             wg_sync();
-            b0.pass0_step(c, nch0);
-            b1.pass0_step(c, nch0);
+            b0.pass0_step(b, nch0);
+            b1.pass0_step(b, nch0);
         }
         if (nch1 == 0) return;
-        for (int c = 0; c <= nch1; c++) {
+        for (int b = 0; b <= nch1 + 1; b++) {
             wg_sync();
-            b0.pass1_step(c, nch1);
-            b1.pass1_step(c, nch1);
+            b0.pass1_step(b, nch1);
+            b1.pass1_step(b, nch1);
         }
     } else {
-        for (int c = 0; c <= nch0; c++) {
+        for (int b = 0; b <= nch0 + 1; b++) {
             wg_sync();
-            b0.pass0_step(c, nch0);
+            b0.pass0_step(b, nch0);
         }
         if (nch1 == 0) return;
-        for (int c = 0; c <= nch1; c++) {
+        for (int b = 0; b <= nch1 + 1; b++) {
             wg_sync();
-            b0.pass1_step(c, nch1);
+            b0.pass1_step(b, nch1);
         }
     }
 }
 
-// WIDE_ONLY: the main kernel's code inside the SECOND launch, for the groups the first launch left to it because a stream has
-// 9..16 taps (two taps per lane of the FIR wave): that path is a different instruction mix and wants a different
-// instruction-scheduler strategy than the 8-tap path (Makefile: SCHED_*), and a kernel has one.
-#ifndef ALAC_WIDE_SPLIT
-#define ALAC_WIDE_SPLIT 1
-#endif
-template <int P, int NS = 8, bool WIDE_ONLY = false>
-__device__ __forceinline__ void ab_kernel_body(const alac_decode_params& p) {
-    static_assert(NS == 8 || (P == 8 && NS == 16), "the dense arrangement exists for the main kernel only");
-    static_assert(!WIDE_ONLY || (P == 8 && NS == 8), "");
-    __shared__ __attribute__((aligned(1024))) AbSharedT<NS> sh;
+// One FIR wave's two passes; the instantiation by what its streams need: rss > 23 anywhere -> the 32-bit multiply and the clamp.
+template <int T, bool SPECIAL, int NS>
+__device__ __forceinline__ void ab_fir_role(const alac_decode_params& p, uint32_t pkt0, int w, int lane, AbSharedT<NS>& sh, int nch0, int nch1,
+                                            bool wide_rss) {
+    if (T < 4 && !wide_rss) {
+        for (int ph = 0; ph < (nch1 > 0 ? 2 : 1); ph++) ab_fir_wave<T, false, false, NS>(p, pkt0, w, lane, sh, ph, ph ? nch1 : nch0);
+    } else {
+        for (int ph = 0; ph < (nch1 > 0 ? 2 : 1); ph++) ab_fir_wave<T, true, SPECIAL, NS>(p, pkt0, w, lane, sh, ph, ph ? nch1 : nch0);
+    }
+}
+
+// TSEL: which groups of 8 packets this body decodes, by the FIR layout they need --
+//   1  first launch, 8-packet workgroups: orders 1..8 (one tap per lane); others are flagged for the second launch
+//   0  first launch, dense arrangement (NS == 16): orders 1..16, one or two taps per lane per FIR wave; others flagged
+//   2  second launch: the groups flagged 3 (some stream with 9..16 taps): two taps per lane
+//   4  second launch: the groups flagged 1 (any order, the delta mode, order 0): four taps per lane
+template <int TSEL, int NS = 8>
+__device__ __forceinline__ void ab_kernel_body(const alac_decode_params& p, AbSharedT<NS>& sh) {
+    static_assert((TSEL == 0) == (NS == 16), "the dense arrangement exists for the first launch only");
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t pkt0 = blockIdx.x * (uint32_t)NS;
-    // ab_flags[group]: 0 = decoded by the first launch (alac_decode_ab_kernel / _dense_kernel); left for the second launch
-    // (alac_decode_ab32_kernel): 1 = to its 32-tap code, 3 = to its copy of the main kernel's two-taps-per-lane code;
-    // 2 / 4 = decoded there.  (The second kernel's entry point looks at the flag and calls the body that goes with it.)
-    // every wave reads all 8 headers: pass lengths (uniform over the workgroup) and whether the P8 layout fits
+    // ab_flags[group]: 0 = decoded by the first launch; left for the second launch (alac_decode_ab32_kernel): 1 = to its
+    // four-taps-per-lane code, 3 = to its two-taps-per-lane code; 2 / 4 = decoded there.
+    // every wave reads all headers: pass lengths (uniform over the workgroup) and which FIR layout fits
     int n0 = 0, n1 = 0;
-    bool bad = false, wide_lane = false;
+    bool bad = false, two_lane = false, wide_lane = false;
     {
         const uint32_t pk = pkt0 + (uint32_t)(lane & (NS - 1));
         const bool v = pk < p.n_packets;
@@ -1057,90 +818,57 @@ __device__ __forceinline__ void ab_kernel_body(const alac_decode_params& p) {
         const bool ok = v && ma.status == 0;
         n0 = ok ? ma.n : 0;
         n1 = (ok && !ma.esc && ma.stereo) ? ma.n : 0;
-        // the main kernel takes LPC orders 1..16; the 32-tap one every order (0 and its neighbours at the masked steps' pace)
-        bad = P == 8 && ok && !ma.esc && (ma.N < 1 || ma.N > 16 || (ma.stereo && (mb.N < 1 || mb.N > 16)));
-        wide_lane = ok && !ma.esc && (ma.N > 8 || (ma.stereo && mb.N > 8));
-        // the parking place needs two ints per sample in the slot (always true for a two-channel stream cfg)
+        // one / two taps per lane take LPC orders 1..16; four taps per lane every order (0 and 31 as modes of the step)
+        bad = TSEL < 4 && ok && !ma.esc && (ma.N < 1 || ma.N > 16 || (ma.stereo && (mb.N < 1 || mb.N > 16)));
+        two_lane = ok && !ma.esc && (ma.N > 8 || (ma.stereo && mb.N > 8));
+        wide_lane = ok && !ma.esc && ma.rss > 23;
+        // the parking place needs two ints per sample in the slot (parse_meta turns anything else into a status)
         bad = bad || (n1 > 0 && (uint64_t)2 * (uint64_t)ma.n > p.slot_ints);
     }
-    if constexpr (P == 16) {
-        // sort the streams of each pass by LPC order (see AbSharedT::stream_at): switched-off streams first (they cost nothing),
-        // then orders 1 .. 30, then the delta mode (31; two-register step only), then order 0 (masked steps: keep them together)
-        for (int ph = 0; ph < 2; ph++) {
-            // (recomputed from the headers every wave has just read; lanes 0..7 hold packet lane & 7)
-            int key;
-            {
-                const uint32_t pk = pkt0 + (uint32_t)(lane & 7);
-                const bool v = pk < p.n_packets;
-                alacgpu_cfg_dev c;
-                const Meta mm = parse_meta(p, pk, ph, v, c);
-                const bool on = v && mm.status == 0 && !mm.esc && (ph == 0 || mm.stereo);
-                key = !on ? 0 : mm.N == 31 ? 40 : mm.N == 0 ? 41 : mm.N;
-            }
-            int rank = 0;
-#pragma unroll
-            for (int j2 = 0; j2 < 8; j2++) {
-                const int kj = __shfl(key, j2, 64);
-                rank += (kj < key || (kj == key && j2 < (lane & 7))) ? 1 : 0;
-            }
-            if (wave == 0 && lane < 8) {
-                sh.stream_at[ph][rank] = (uint8_t)lane;
-                sh.row_of[ph][lane] = (uint8_t)rank;
-            }
-        }
-    }
     const bool fallback = __builtin_amdgcn_ballot_w64(bad) != 0;
-    // some stream (of the block of 8 a FIR wave serves) has more than 8 taps: two taps per lane
-    const bool wide = __builtin_amdgcn_ballot_w64(wide_lane && (lane & (NS - 1)) < 8) != 0;
-    const bool wide1 = NS > 8 && __builtin_amdgcn_ballot_w64(wide_lane && (lane & (NS - 1)) >= 8) != 0;
-    // (8-packet arrangement only: the dense one keeps its two-taps-per-lane groups)
-    const bool hand_over = P == 8 && NS == 8 && !WIDE_ONLY && ALAC_WIDE_SPLIT && p.ab_flags && wide && !fallback;
-    if (P == 8 && !WIDE_ONLY) {
+    // some stream (of the block of 8 a FIR wave serves) has more than 8 taps / more than 23 bits
+    const bool two0 = __builtin_amdgcn_ballot_w64(two_lane && (lane & (NS - 1)) < 8) != 0;
+    const bool two1 = NS > 8 && __builtin_amdgcn_ballot_w64(two_lane && (lane & (NS - 1)) >= 8) != 0;
+    const bool wrss0 = __builtin_amdgcn_ballot_w64(wide_lane && (lane & (NS - 1)) < 8) != 0;
+    const bool wrss1 = NS > 8 && __builtin_amdgcn_ballot_w64(wide_lane && (lane & (NS - 1)) >= 8) != 0;
+    if (TSEL <= 1) {
+        // (8-packet arrangement: groups with 9..16 taps go to the second launch; the dense one keeps them)
+        const bool hand_over = TSEL == 1 && two0 && !fallback;
         if (p.ab_flags && threadIdx.x == 0) {   // one flag per 8 packets (the second launch works in groups of 8)
             const uint32_t f0 = blockIdx.x * (uint32_t)(NS / 8);
             p.ab_flags[f0] = fallback ? 1u : hand_over ? 3u : 0u;
             if (NS > 8 && pkt0 + 8u < p.n_packets) p.ab_flags[f0 + 1] = fallback ? 1u : 0u;
         }
-        if (hand_over) return;
-    } else if (WIDE_ONLY) {
-        if (threadIdx.x == 0) p.ab_flags[blockIdx.x] = 4u;
+        if (hand_over || fallback) return;
     } else {
-        if (!fallback && threadIdx.x == 0) p.ab_flags[blockIdx.x] = 2u;
-        // Nothing is launched behind this kernel in auto mode.  What it cannot take would be a two-channel packet without
-        // room for parking in its slot -- which cannot pass the header check (parse_meta: two channels only in a
-        // two-channel stream cfg, and then 2 n <= slot_ints).  Should that ever change, fail loudly rather than skip:
-        if (fallback && threadIdx.x < (unsigned)NS && pkt0 + threadIdx.x < p.n_packets) {
-            p.status[pkt0 + threadIdx.x] = ALACGPU_ST_UNSUPPORTED_PARAMS_D;
-            if (p.out_bytes) p.out_bytes[pkt0 + threadIdx.x] = 0;
-            if (p.out_samples) p.out_samples[pkt0 + threadIdx.x] = 0;
+        if (threadIdx.x == 0) p.ab_flags[blockIdx.x] = TSEL == 2 ? 4u : 2u;
+        // Nothing is launched behind this kernel.  What the four-taps body cannot take would be a two-channel packet without
+        // room for parking in its slot -- parse_meta turns that into a status.  Should that ever change, fail loudly:
+        if (fallback) {
+            if (threadIdx.x < (unsigned)NS && pkt0 + threadIdx.x < p.n_packets) {
+                p.status[pkt0 + threadIdx.x] = ALACGPU_ST_UNSUPPORTED_PARAMS_D;
+                if (p.out_bytes) p.out_bytes[pkt0 + threadIdx.x] = 0;
+                if (p.out_samples) p.out_samples[pkt0 + threadIdx.x] = 0;
+            }
+            return;
         }
     }
-    if (fallback) return;
     const int nch0 = (__builtin_amdgcn_readfirstlane(wave_max(n0)) + AB_CHUNK - 1) / AB_CHUNK;
     const int nch1 = (__builtin_amdgcn_readfirstlane(wave_max(n1)) + AB_CHUNK - 1) / AB_CHUNK;
-    for (int t = threadIdx.x; t < AB_CHUNK * NS; t += blockDim.x) (&sh.zeros[0][0])[t] = 0;
-    if (p.dbg && lane == 0) {   // diagnostic (ALACGPU_DEBUG_STAMPS): where each wave runs, when the workgroup starts
-        if (wave == 0) {
-#ifndef ALAC_DIAG
-            const unsigned hw = __builtin_amdgcn_s_getreg(63492), xcc = __builtin_amdgcn_s_getreg(63508);
-            p.dbg[8 * blockIdx.x + 4] = ((unsigned long long)xcc << 32) | hw;
-#endif
-            p.dbg[8 * blockIdx.x + 0] = clock64();
-        }
-    }
+    // the zero column of the converted queue
+    for (int t = threadIdx.x; t < 2 * AB_CHUNK; t += blockDim.x) xq_zero(sh.xq[t / AB_CHUNK][t % AB_CHUNK][NS]);
+    DIAG_ONLY(if (p.dbg && threadIdx.x == 0) {
+        p.dbg[8 * blockIdx.x + 3] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492);
+        p.dbg[8 * blockIdx.x + 0] = clock64();
+    })
     // Who does what.  A heavy wave (entropy, FIR) should share its SIMD with an output wave at most: where two heavy waves of
     // different workgroups share one, those workgroups take 30 % longer, and the launch ends with its slowest workgroup.
     // Where the dispatcher puts the waves depends on what ran before (even on the kernel launched before this one: measured,
     // one XCD's worth of CUs ended up with clashing pairs and cfg2 took 1.05 instead of 0.81 ms), so the roles do not go
-    // by wave index: every workgroup has one wave on each of the CU's four SIMDs (the main kernel brings a fourth wave
-    // for that, which leaves at once), takes its turn k on the CU from a counter, and puts entropy on SIMD k, output on
-    // k + 1, FIR on k + 2 (the 32-tap kernel: its FIR waves on k + 2 and k + 3).  Workgroups with consecutive turns so
+    // by wave index: every workgroup has one wave on each of the CU's four SIMDs (the 8-packet arrangement brings a fourth
+    // wave for that, which leaves at once), takes its turn k on the CU from a counter, and puts entropy on SIMD k, output on
+    // k + 1, FIR on k + 2 (the dense arrangement: its second FIR wave on k + 3).  Workgroups with consecutive turns so
     // never pair two heavy waves; four per CU load every SIMD alike.
-#ifndef ALAC_DIAG
-    if (p.dbg && lane == 0 && wave < 3)
-        p.dbg[8 * blockIdx.x + (wave == 0 ? 3 : wave == 1 ? 5 : 6)] =
-            ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492);
-#endif
     int role = wave;
     if (p.cu_arrivals) {
         const uint32_t hw = __builtin_amdgcn_s_getreg(63492);                       // HW_ID
@@ -1152,40 +880,24 @@ __device__ __forceinline__ void ab_kernel_body(const alac_decode_params& p) {
         if (lane == 0) sh.ring_on[wave] = my_simd;
         wg_sync();
         const uint32_t used = (1u << sh.ring_on[0]) | (1u << sh.ring_on[1]) | (1u << sh.ring_on[2]) | (1u << sh.ring_on[3]);
-        if (used == 15u) {                                                          // (else: not one wave per SIMD -- wave order)
-            // the 32-tap kernel has four working waves, two of them FIR: with up to two workgroups per CU a step of two
-            // SIMDs per turn pairs every FIR wave with an entropy or an output wave instead of another FIR wave
-            const uint32_t step = (P == 16 && gridDim.x <= 512u) ? 2u : 1u;
-            role = (int)((my_simd - step * sh.ring_next[NS - 1]) & 3u);
-        }
+        if (used == 15u) role = (int)((my_simd - sh.ring_next[NS - 1]) & 3u);       // (else: not one wave per SIMD -- wave order)
     }
-    if (P == 8 && NS == 8 && role == 3) return;     // the main kernel's fourth wave was only there to claim the fourth SIMD
+    if (NS == 8 && role == 3) return;     // the fourth wave was only there to claim the fourth SIMD
     wg_sync();
     if (role == 0) {
         __builtin_amdgcn_s_setprio(ALAC_ENTROPY_PRIO);
-        ab_entropy_wave<P, NS>(p, pkt0, lane, sh, nch0, nch1);
-        if (p.dbg && lane == 0) p.dbg[8 * blockIdx.x + 2] = clock64();
+        ab_entropy_wave<NS>(p, pkt0, lane, sh, nch0, nch1);
     } else if (role == 1) {
-        ab_output_wave<P, NS>(p, pkt0, lane, sh, nch0, nch1);
-    } else if constexpr (NS == 16) {
-        // dense arrangement: the fourth wave works too -- FIR waves for streams 0..7 (role 2) and 8..15 (role 3)
-        __builtin_amdgcn_s_setprio(1);
-        const int w = role - 2;
-        if (__builtin_expect(!(w ? wide1 : wide), 1)) {
-            for (int ph = 0; ph < (nch1 > 0 ? 2 : 1); ph++) ab_fir_wave<NS>(p, pkt0, w, lane, sh, ph, ph ? nch1 : nch0);
-        } else {
-            for (int ph = 0; ph < (nch1 > 0 ? 2 : 1); ph++) ab_fir_wave2<NS>(p, pkt0, w, lane, sh, ph, ph ? nch1 : nch0);
-        }
-    } else if constexpr (P == 16) {
-        __builtin_amdgcn_s_setprio(1);   // above the output waves, below the entropy waves (8192 packets: 1.074 -> 1.048 ms, cfg3 3.33 -> 3.25)
-        for (int ph = 0; ph < (nch1 > 0 ? 2 : 1); ph++) ab_fir16_wave(p, pkt0, role - 2, lane, sh, ph, ph ? nch1 : nch0);
+        ab_output_wave<NS>(p, pkt0, lane, sh, nch0, nch1);
     } else {
         __builtin_amdgcn_s_setprio(1);   // above the output waves, below the entropy waves (8192 packets: 1.074 -> 1.048 ms, cfg3 3.33 -> 3.25)
-        if (!WIDE_ONLY && __builtin_expect(!wide, 1)) {
-            for (int ph = 0; ph < (nch1 > 0 ? 2 : 1); ph++) ab_fir_wave<NS>(p, pkt0, 0, lane, sh, ph, ph ? nch1 : nch0);
-        } else {
-            for (int ph = 0; ph < (nch1 > 0 ? 2 : 1); ph++) ab_fir_wave2<NS>(p, pkt0, 0, lane, sh, ph, ph ? nch1 : nch0);
-        }
+        const int w = role - 2;
+        const bool wr = w ? wrss1 : wrss0;
+        if constexpr (TSEL == 4) ab_fir_role<4, true, NS>(p, pkt0, w, lane, sh, nch0, nch1, true);
+        else if constexpr (TSEL == 2) ab_fir_role<2, false, NS>(p, pkt0, w, lane, sh, nch0, nch1, wr);
+        else if constexpr (TSEL == 1) ab_fir_role<1, false, NS>(p, pkt0, w, lane, sh, nch0, nch1, wr);
+        else if (__builtin_expect(!(w ? two1 : two0), 1)) ab_fir_role<1, false, NS>(p, pkt0, w, lane, sh, nch0, nch1, wr);
+        else ab_fir_role<2, false, NS>(p, pkt0, w, lane, sh, nch0, nch1, wr);
     }
 }
 
@@ -1195,34 +907,45 @@ __device__ __forceinline__ void ab_kernel_body(const alac_decode_params& p) {
 // the instruction-scheduler settings it measured best with (Makefile: SCHED_*).  Without ALAC_EMIT all of them are emitted.
 #if !defined(ALAC_EMIT) || ALAC_EMIT == 1
 // The main kernel for batches whose workgroups fit the chip four per CU (up to 10240 packets): 128 registers, nothing spilled.
-extern "C" __global__ __launch_bounds__(256, 4) void alac_decode_ab_kernel(alac_decode_params p) { ab_kernel_body<8>(p); }
+extern "C" __global__ __launch_bounds__(256, 4) void alac_decode_ab_kernel(alac_decode_params p) {
+    __shared__ __attribute__((aligned(1024))) AbSharedT<8> sh;
+    ab_kernel_body<1>(p, sh);
+}
 #endif
 #if !defined(ALAC_EMIT) || ALAC_EMIT == 5
 // The same as alac_decode_ab_kernel, its object compiled with speculative units of 16 steps (-DALAC_SPEC_UNIT=16), for batches
 // of up to 4096 packets: the entropy wave's straight-line blocks are twice as long and the code between units runs half as
-// often (every workgroup -3 %), a failed unit costs twice as much (the slowest workgroup -1 %): -2.2 % where the launch is
-// bound by one packet's chain, +2 % from 5120 packets on, where wasted instructions count.
-extern "C" __global__ __launch_bounds__(256, 4) void alac_decode_ab_small_kernel(alac_decode_params p) { ab_kernel_body<8>(p); }
+// often, a failed unit costs twice as much: better where the launch is bound by one packet's chain, worse from 5120 packets
+// on, where wasted instructions count.
+extern "C" __global__ __launch_bounds__(256, 4) void alac_decode_ab_small_kernel(alac_decode_params p) {
+    __shared__ __attribute__((aligned(1024))) AbSharedT<8> sh;
+    ab_kernel_body<1>(p, sh);
+}
 #endif
 #if !defined(ALAC_EMIT) || ALAC_EMIT == 4
 // The same with 96 registers, for the batches in between (10241 .. 12288 packets): five workgroups per CU instead of four
-// once a batch has more than fit at once (12288 packets: 1.43 against 1.71 ms); the scratch it then needs (the max-ilp
-// scheduling raises the register pressure: 116 bytes per lane) costs the small batches 1.5 %, which is why they have their own.
-extern "C" __global__ __launch_bounds__(256, 5) void alac_decode_ab5_kernel(alac_decode_params p) { ab_kernel_body<8>(p); }
+// once a batch has more than fit at once.
+extern "C" __global__ __launch_bounds__(256, 5) void alac_decode_ab5_kernel(alac_decode_params p) {
+    __shared__ __attribute__((aligned(1024))) AbSharedT<8> sh;
+    ab_kernel_body<1>(p, sh);
+}
 #endif
 #if !defined(ALAC_EMIT) || ALAC_EMIT == 2
-// LPC orders up to 31 (and the delta mode): two FIR waves in the 16-lane layout with two tap registers, four packets each
-// -- and the groups of the main kernel with 9..16 taps (see ab_kernel_body: WIDE_ONLY)
+// The second launch: the groups the first one flagged -- two taps per lane (orders 9..16), four (anything else)
 extern "C" __global__ __launch_bounds__(256) void alac_decode_ab32_kernel(alac_decode_params p) {
-    const uint32_t f = p.ab_flags ? p.ab_flags[blockIdx.x] : 0u;
-    if (f == 1u) ab_kernel_body<16>(p);
-    else if (f == 3u) ab_kernel_body<8, 8, true>(p);
+    __shared__ __attribute__((aligned(1024))) AbSharedT<8> sh;
+    const uint32_t f = p.ab_flags ? p.ab_flags[blockIdx.x] : 1u;
+    if (f == 1u) ab_kernel_body<4>(p, sh);
+    else if (f == 3u) ab_kernel_body<2>(p, sh);
 }
 #endif
 #if !defined(ALAC_EMIT) || ALAC_EMIT == 3
-// The main kernel's dense arrangement for big batches: 16 packets per 256-thread workgroup: one entropy wave for all 16
-// streams (4 lanes each), one output wave for all 16, two FIR waves of 8 streams -- one wave per SIMD, roles by SIMD and turn
-// as above.  Same results, about a fifth fewer instructions per sample; a step of its entropy wave takes as long as the
-// 8-stream one's, so small (latency-bound) batches gain nothing.
-extern "C" __global__ __launch_bounds__(256, 4) void alac_decode_ab_dense_kernel(alac_decode_params p) { ab_kernel_body<8, 16>(p); }
+// The dense arrangement for big batches: 16 packets per 256-thread workgroup: one entropy wave for all 16 streams (4 lanes
+// each), one output wave for all 16, two FIR waves of 8 streams -- one wave per SIMD, roles by SIMD and turn as above.  Same
+// results, fewer instructions per sample; a step of its entropy wave takes as long as the 8-stream one's, so small
+// (latency-bound) batches gain nothing.
+extern "C" __global__ __launch_bounds__(256, 4) void alac_decode_ab_dense_kernel(alac_decode_params p) {
+    __shared__ __attribute__((aligned(1024))) AbSharedT<16> sh;
+    ab_kernel_body<0, 16>(p, sh);
+}
 #endif

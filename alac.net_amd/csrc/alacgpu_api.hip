@@ -154,7 +154,9 @@ int fill_params(alacgpu_ctx* ctx, alac_decode_params& p, const void* d_blob, uin
     p.out_samples = (int32_t*)d_out_samples;
     p.status = (int32_t*)d_status;
     p.out_format = ctx->out_format;
+#ifdef ALAC_DIAG
     p.dbg = nullptr;
+#endif
     p.ab_flags = nullptr;
     p.cu_arrivals = nullptr;
     return ALACGPU_OK;
@@ -317,6 +319,7 @@ int alacgpu_decode_batch_device(alacgpu_ctx* ctx, const void* d_blob, uint64_t b
     return launch(ctx, p, (hipStream_t)hip_stream);
 }
 
+#ifdef ALAC_DIAG
 // Diagnostic twin of alacgpu_decode_batch_device (not part of include/alacgpu.h; tools/ only): the kernels additionally
 // write 8 clock / placement stamps per workgroup into d_stamps (8 * ceil(n_packets / 8) uint64, zeroed by the caller).
 int alacgpu_dbg_decode_batch_device_stamps(alacgpu_ctx* ctx, const void* d_blob, uint64_t blob_bytes, const void* d_offsets,
@@ -333,6 +336,7 @@ int alacgpu_dbg_decode_batch_device_stamps(alacgpu_ctx* ctx, const void* d_blob,
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     return launch(ctx, p, (hipStream_t)hip_stream);
 }
+#endif
 
 // Host buffers: the batch is cut into contiguous packet ranges (two by default, up to four), each on its own stream, so that
 // the H2D copy of range k+1, the decode of range k and the D2H copy of range k-1 overlap (the two copy directions use
