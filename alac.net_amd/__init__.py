@@ -57,6 +57,17 @@ SYMBOLS = {
     "alacgpu_strerror": (C.c_char_p, [C.c_int]),
     "alacgpu_status_string": (C.c_char_p, [C.c_int]),
     "alacgpu_last_error": (C.c_char_p, [_VP]),
+    "alacgpu_ctx_device": (C.c_int, [_VP]),
+    "alacgpu_shard_ranges": (C.c_int, [_VP, C.c_uint32, C.c_uint32, _VP]),
+    "alacgpu_comm_get_unique_id": (C.c_int, [_VP]),
+    "alacgpu_comm_create": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.POINTER(_VP)]),
+    "alacgpu_comm_destroy": (None, [_VP]),
+    "alacgpu_comm_rank": (C.c_int, [_VP]),
+    "alacgpu_comm_world": (C.c_int, [_VP]),
+    "alacgpu_comm_last_error": (C.c_char_p, [_VP]),
+    "alacgpu_allgather_pcm": (C.c_int, [_VP, _VP, _VP, C.c_uint32, _VP]),
+    "alacgpu_decode_allgather_device": (C.c_int, [_VP, _VP, _VP, C.c_uint64, _VP, _VP, _VP, _VP, _VP, C.c_uint32, _VP, _VP, _VP,
+                                                  C.c_uint32, _VP]),
 }
 
 
@@ -201,6 +212,77 @@ class AlacGpuContext:
                                         C.byref(st))
         _check(rc, self._ctx)
         return out, ob.value, st.value
+
+
+def shard_ranges(sizes, world):
+    """alacgpu_shard_ranges: the packet partition of every multi-GPU entry point -- contiguous ranges cut at multiples of 8
+    packets, balanced by packet bytes.  Returns first[world + 1]; rank r owns packets first[r] .. first[r+1].  Host arithmetic."""
+    sizes = np.ascontiguousarray(sizes, dtype=np.uint32)
+    first = np.zeros(world + 1, dtype=np.uint32)
+    _check(lib().alacgpu_shard_ranges(_ptr(sizes), len(sizes), world, _ptr(first)))
+    return first
+
+
+class AlacGpuComm:
+    """alacgpu_comm: this rank's handle on the RCCL communicator for the all-gather of decoded PCM (one process per GPU).
+    `unique_id()` on rank 0, hand the 128 bytes to the other ranks (torch.distributed broadcast, a file, MPI ...), then
+    every rank constructs AlacGpuComm(ctx, id, rank, world) -- a collective call."""
+
+    @staticmethod
+    def unique_id():
+        buf = np.zeros(128, dtype=np.uint8)
+        rc = lib().alacgpu_comm_get_unique_id(_ptr(buf))
+        if rc != 0:
+            raise AlacGpuError(f"alacgpu rc={rc}: {lib().alacgpu_strerror(rc).decode()} ({lib().alacgpu_comm_last_error(None).decode()})")
+        return buf
+
+    def __init__(self, ctx, unique_id, rank, world):
+        self._comm = _VP()
+        self.ctx, self.rank, self.world = ctx, rank, world
+        uid = np.ascontiguousarray(unique_id, dtype=np.uint8)
+        assert uid.size == 128
+        rc = lib().alacgpu_comm_create(ctx._ctx, _ptr(uid), rank, world, C.byref(self._comm))
+        if rc != 0:
+            self._comm = _VP()
+            raise AlacGpuError(f"alacgpu rc={rc}: {lib().alacgpu_strerror(rc).decode()} ({lib().alacgpu_comm_last_error(None).decode()})")
+
+    def _check(self, rc):
+        if rc != 0:
+            raise AlacGpuError(f"alacgpu rc={rc}: {lib().alacgpu_strerror(rc).decode()} ({lib().alacgpu_comm_last_error(self._comm).decode()})")
+
+    def allgather_pcm(self, d_full, first, slot_ints, stream=0):
+        """d_full: torch int32 CUDA tensor [n_packets, slot_ints] holding this rank's packets first[rank]..first[rank+1]
+        decoded in place; asynchronous on `stream` (raw hipStream_t)."""
+        first = np.ascontiguousarray(first, dtype=np.uint32)
+        self._check(lib().alacgpu_allgather_pcm(self._comm, _VP(d_full.data_ptr()), _ptr(first), slot_ints, _VP(stream)))
+
+    def decode_allgather_device(self, d_blob, blob_bytes, d_offsets, d_sizes, d_cfg_idx, first, d_full, slot_ints, d_out_bytes,
+                                d_out_samples, d_status, n_chunks=4, stream=0):
+        """Decode this rank's range (device arrays indexed by GLOBAL packet number) in n_chunks pieces and gather piece k
+        while piece k+1 decodes; asynchronous on `stream`."""
+        def dp(t):
+            return _VP(t.data_ptr()) if t is not None else None
+        first = np.ascontiguousarray(first, dtype=np.uint32)
+        self._check(lib().alacgpu_decode_allgather_device(self.ctx._ctx, self._comm, dp(d_blob), blob_bytes, dp(d_offsets), dp(d_sizes),
+                                                          dp(d_cfg_idx), _ptr(first), dp(d_full), slot_ints, dp(d_out_bytes),
+                                                          dp(d_out_samples), dp(d_status), n_chunks, _VP(stream)))
+
+    def close(self):
+        if self._comm:
+            lib().alacgpu_comm_destroy(self._comm)
+            self._comm = _VP()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def decode_batch_sharded(contexts, blob, offsets, sizes, cfg_idx=None, slot_ints=None, out=None):

@@ -75,6 +75,22 @@ constexpr int FULL_HOLD = ALAC_FULL_HOLD;
 #define ALAC_ESC_HOLD 1
 #endif
 constexpr int ESC_HOLD = ALAC_ESC_HOLD;
+// Escape codes that keep coming (a loud passage whose peaks escape every few units: 90 of a packet's 512 units in the slowest
+// workgroups of cfg2) are cheaper on the escape tier throughout than as one failed plain unit each: when a plain unit fails
+// within ESC_NEAR units of the last escape code, the wave stays on the escape tier until ESC_LONG units in a row were clean.
+// (Measured, profiles/experiments/r3_adaptive_escape_hold.txt: 8 / 8 in the small-batch build -2 % on cfg2 at 4096 packets;
+// the other builds keep NEAR = 0, i.e. the fixed hold.)
+#ifndef ALAC_ESC_NEAR
+#define ALAC_ESC_NEAR 0
+#endif
+#ifndef ALAC_ESC_LONG
+#define ALAC_ESC_LONG 1
+#endif
+struct TierState {
+    int full_left;   // units still to decode on an escape-capable tier
+    int hold;        // clean units the escape tier waits for before handing back to the plain tier
+    int since;       // units since the last escape code
+};
 
 // After a tier-1-like pass: the parked lanes (see spec_unit) drop out of the verdict and get their state back.
 template <bool WANT_R, int QSTRIDE>
@@ -95,7 +111,7 @@ __device__ __forceinline__ void spec_unpark(Rice& rs, const Rice& snap, bool par
 }
 
 template <bool WANT_R, int QSTRIDE, bool RAW = false>
-__device__ __forceinline__ bool spec_unit(Rice& rs, int& full_left, const RiceCfg& c, uint32_t ring, int* q, SpecStats& st) {
+__device__ __forceinline__ bool spec_unit(Rice& rs, TierState& ts, const RiceCfg& c, uint32_t ring, int* q, SpecStats& st) {
     const Rice snap = rs;
     // A stream whose zero run covers the whole unit is PARKED: its lanes run the plain code with everybody else (on
     // whatever their window shows -- harmless, see rice_spec_step), are left out of the unit's verdict and get their state
@@ -104,7 +120,7 @@ __device__ __forceinline__ bool spec_unit(Rice& rs, int& full_left, const RiceCf
     const bool special = __builtin_amdgcn_ballot_w64(rs.nforce == 0u && !parked) != 0;
     uint32_t xmax = 0, vmax = 0;
     int hmin = 0x7FFFFFFF;
-    if (full_left == 0) {
+    if (ts.full_left == 0) {
         if (!special) {
 #pragma unroll
             for (int ii = 0; ii < SPEC_UNIT; ii++) {
@@ -124,11 +140,12 @@ __device__ __forceinline__ bool spec_unit(Rice& rs, int& full_left, const RiceCf
         const bool newrun = __builtin_amdgcn_ballot_w64(hmin < 128) != 0;
         // an escape code -- or a value whose history update needs the clamp the plain step leaves out
         const bool sawesc = __builtin_amdgcn_ballot_w64(xmax > 8u || vmax > 0xFFFFu) != 0;
-        if (__builtin_expect(!newrun && !sawesc, 1)) { if (special) SPEC_COUNT(z_units); else SPEC_COUNT(plain_ok); return true; }
+        if (__builtin_expect(!newrun && !sawesc, 1)) { if (special) SPEC_COUNT(z_units); else SPEC_COUNT(plain_ok); ts.since++; return true; }
         rs = snap;
         if (newrun) { SPEC_COUNT(fail_run); return false; }          // no tier can do it
         SPEC_COUNT(fail_esc);
-        full_left = 1;                     // escapes: go on with an escape-capable tier
+        ts.full_left = 1;                  // escapes: go on with an escape-capable tier
+        ts.hold = ts.since < ALAC_ESC_NEAR ? ALAC_ESC_LONG : ESC_HOLD;
         xmax = 0;
         hmin = 0x7FFFFFFF;
     }
@@ -140,7 +157,8 @@ __device__ __forceinline__ bool spec_unit(Rice& rs, int& full_left, const RiceCf
         }
         spec_unpark<WANT_R, QSTRIDE>(rs, snap, parked, xmax, hmin, q);
         const bool sawesc = __builtin_amdgcn_ballot_w64(xmax > 8u) != 0;
-        full_left = sawesc ? ESC_HOLD : full_left - 1;
+        ts.full_left = sawesc ? ts.hold : ts.full_left - 1;
+        ts.since = sawesc ? 0 : ts.since + 1;
         SPEC_COUNT(esc_units);
     } else if (!special) {                 // tier 1E for wide raw values (24-bit streams)
         uint32_t w3 = lds_load(((rs.ra + 4u) & RING_MASK) | ring);
@@ -151,7 +169,8 @@ __device__ __forceinline__ bool spec_unit(Rice& rs, int& full_left, const RiceCf
         }
         spec_unpark<WANT_R, QSTRIDE>(rs, snap, parked, xmax, hmin, q);
         const bool sawesc = __builtin_amdgcn_ballot_w64(xmax > 8u) != 0;
-        full_left = sawesc ? ESC_HOLD : full_left - 1;
+        ts.full_left = sawesc ? ts.hold : ts.full_left - 1;
+        ts.since = sawesc ? 0 : ts.since + 1;
         SPEC_COUNT(esc_units);
     } else {                               // tier 3
         uint32_t w3 = lds_load(((rs.ra + 4u) & RING_MASK) | ring);
@@ -162,7 +181,8 @@ __device__ __forceinline__ bool spec_unit(Rice& rs, int& full_left, const RiceCf
         }
         rs.nforce = (rs.zrun > 0 || rs.signmod != 0) ? 0u : 0xFFFFFFFFu;
         const bool sawesc = __builtin_amdgcn_ballot_w64(xmax > 8u) != 0;
-        full_left = sawesc ? FULL_HOLD : full_left - 1;
+        ts.full_left = sawesc ? FULL_HOLD : ts.full_left - 1;
+        ts.since = sawesc ? 0 : ts.since + 1;
         SPEC_COUNT(full_units);
     }
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(hmin < 128) != 0, 0)) {
@@ -238,7 +258,10 @@ __device__ __forceinline__ uint32_t ab_entropy_pass(const alac_decode_params& p,
     int flags = 0;
     // every stream's first value is coded against the initial history (a small k): as a rule an escape code -- the pass
     // starts on the escape tier instead of failing its first plain unit
-    int full_left = 1;
+    TierState ts;
+    ts.full_left = 1;
+    ts.hold = ESC_HOLD;
+    ts.since = ALAC_ESC_NEAR;
 #ifndef ALAC_DIAG
     SpecStats st;
 #endif
@@ -339,7 +362,7 @@ __device__ __forceinline__ uint32_t ab_entropy_pass(const alac_decode_params& p,
                 int* q = qa + (c & 1) * qodd;
 #pragma unroll
                 for (int u = 0; u < AB_CHUNK; u += SPEC_UNIT) {
-                    const bool redo = !spec_unit<true, S, true>(rs, full_left, kc, kring, q + u * S, st);
+                    const bool redo = !spec_unit<true, S, true>(rs, ts, kc, kring, q + u * S, st);
                     if (__builtin_expect(redo, 0)) {
                         SPEC_COUNT(redo);
                         for (int ii = 0; ii < SPEC_UNIT; ii++) {
@@ -364,7 +387,7 @@ __device__ __forceinline__ uint32_t ab_entropy_pass(const alac_decode_params& p,
                 if (fast_chunk) {
 #pragma unroll
                     for (int u = 0; u < AB_CHUNK; u += SPEC_UNIT) {
-                        const bool redo = !spec_unit<true, S, true>(rs, full_left, kc, kring, q + u * S, st);
+                        const bool redo = !spec_unit<true, S, true>(rs, ts, kc, kring, q + u * S, st);
                         if (redo) {
                             SPEC_COUNT(redo);
                             for (int ii = 0; ii < SPEC_UNIT; ii++) {

@@ -85,9 +85,11 @@ int ensure_ws(alacgpu_ctx* ctx, size_t bytes) {
     return ALACGPU_OK;
 }
 
-// The two-pass kernels: the main one decodes the groups of 8 packets whose streams have LPC order 1..16 and flags the
-// others for the 32-tap arrangement launched right behind it on the same stream (a two-channel packet passes the header
-// check only in a two-channel stream cfg, where its slot has room for parking; the kernel reports a status otherwise).
+// The two-pass kernels: the first launch decodes the groups of 8 packets whose streams have LPC order 1..8 (the dense
+// arrangement: 1..16) and flags the others for the second launch right behind it on the same stream (two or four taps per
+// lane of the FIR wave).  A two-channel element needs room for parking channel A in its slot (2 n <= slot_ints): parse_meta
+// turns anything else into a per-packet status, also a two-channel element in a one-channel stream cfg, which is decoded
+// (its left channel comes out, AlacFile.cs:353-354) when the slot has that room.
 int launch(alacgpu_ctx* ctx, const alac_decode_params& p_in, hipStream_t stream) {
     if (p_in.n_packets == 0) return ALACGPU_OK;
     alac_decode_params p = p_in;
@@ -186,6 +188,7 @@ const char* alacgpu_strerror(int rc) {
     case ALACGPU_ERR_HIP: return "HIP runtime error";
     case ALACGPU_ERR_UNSUPPORTED_CONFIG: return "stream configuration outside the supported domain";
     case ALACGPU_ERR_NO_MEMORY: return "out of memory";
+    case ALACGPU_ERR_COMM: return "RCCL unavailable or a collective failed";
     default: return "unknown error";
     }
 }
@@ -205,6 +208,8 @@ const char* alacgpu_status_string(int st) {
 }
 
 const char* alacgpu_last_error(alacgpu_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null ctx"; }
+
+int alacgpu_ctx_device(const alacgpu_ctx* ctx) { return ctx ? ctx->device : -1; }
 
 int alacgpu_device_count(void) {
     int ndev = 0;
@@ -248,7 +253,7 @@ int alacgpu_create(const alacgpu_cfg* cfgs, uint32_t n_cfgs, int device, alacgpu
     if (!ctx) return ALACGPU_ERR_NO_MEMORY;
     ctx->device = device;
     ctx->n_cfgs = n_cfgs;
-    if (const char* v = std::getenv("ALACGPU_DENSE")) ctx->dense = std::max(0, std::min(std::atoi(v), 4));
+    if (const char* v = std::getenv("ALACGPU_DENSE")) ctx->dense = std::max(-1, std::min(std::atoi(v), 4));   // negative: auto
     if (const char* v = std::getenv("ALACGPU_HOST_CHUNKS")) ctx->host_chunks = std::max(0, std::min(std::atoi(v), N_HOST_STREAMS));
     int rc = ALACGPU_OK;
     do {
@@ -449,6 +454,9 @@ int alacgpu_decode_batch_sharded(alacgpu_ctx* const* ctxs, uint32_t n_ctxs, cons
                                  int32_t* pcm_out, uint32_t slot_ints, int32_t* out_bytes, int32_t* out_samples, int32_t* status) {
     if (!ctxs || n_ctxs == 0) return ALACGPU_ERR_BAD_ARG;
     for (uint32_t r = 0; r < n_ctxs; r++)
+        for (uint32_t q = 0; q < r; q++)
+            if (ctxs[q] == ctxs[r]) return ALACGPU_ERR_BAD_ARG;   // one context on two threads would race
+    for (uint32_t r = 0; r < n_ctxs; r++)
         if (!ctxs[r] || ctxs[r]->n_cfgs != ctxs[0]->n_cfgs || ctxs[r]->out_format != ctxs[0]->out_format) return ALACGPU_ERR_BAD_ARG;
     if (n_packets == 0) return ALACGPU_OK;
     if (!blob || !offsets || !sizes || !pcm_out || !status || slot_ints == 0) return ALACGPU_ERR_BAD_ARG;
@@ -456,10 +464,7 @@ int alacgpu_decode_batch_sharded(alacgpu_ctx* const* ctxs, uint32_t n_ctxs, cons
         return alacgpu_decode_batch(ctxs[0], blob, blob_bytes, offsets, sizes, cfg_idx, n_packets, pcm_out, slot_ints, out_bytes,
                                     out_samples, status);
     std::vector<uint32_t> lo(n_ctxs + 1);
-    for (uint32_t r = 0; r <= n_ctxs; r++)
-        lo[r] = std::min<uint64_t>(n_packets, (((uint64_t)n_packets * r / n_ctxs) + 7u) & ~7ull);
-    lo[0] = 0;
-    lo[n_ctxs] = n_packets;
+    if (alacgpu_shard_ranges(sizes, n_packets, n_ctxs, lo.data()) != ALACGPU_OK) return ALACGPU_ERR_BAD_ARG;
     std::vector<int> rcs(n_ctxs, ALACGPU_OK);
     std::vector<std::thread> workers;
     workers.reserve(n_ctxs);

@@ -9,16 +9,45 @@ xGMI when the backend is nccl; gloo on CPU for the tests).
 import numpy as np
 
 
-def shard_range(n_packets, rank, world):
-    """Contiguous range [lo, hi) of rank `rank`; ranges differ by at most one packet."""
+def shard_ranges(sizes, world):
+    """first[world + 1]: rank r owns packets first[r] .. first[r+1].  Contiguous ranges, cut at multiples of 8 packets (the
+    kernels work in groups of 8): equal packet COUNTS where that leaves the ranges' bytes within 5 % of each other (equal
+    shards gather with one plain all-gather), else balanced by cumulative packet BYTES ("if packet
+    sizes are skewed").  Same arithmetic as the library's alacgpu_shard_ranges (tests/test_distributed_gloo.py compares
+    the two); kept in Python too so that a rank can partition before it loads anything."""
+    sizes = np.asarray(sizes, dtype=np.uint64)
+    n = len(sizes)
+    first = np.array([min(n, ((n * r // world) + 7) & ~7) for r in range(world + 1)], dtype=np.uint32)
+    first[0], first[world] = 0, n
+    by = [int(sizes[first[r]:first[r + 1]].sum()) for r in range(world)]
+    if max(by) * 100 <= min(by) * 105:
+        return first
+    total = int(sizes.sum())
+    groups = [int(sizes[i:i + 8].sum()) for i in range(0, n, 8)]
+    acc, gi = 0, 0
+    for r in range(1, world):
+        want = total * r // world
+        while gi < len(groups) and acc + groups[gi] // 2 <= want:
+            acc += groups[gi]
+            gi += 1
+        first[r] = min(n, gi * 8)
+    first[world] = n
+    return np.maximum.accumulate(first)
+
+
+def shard_range(n_packets, rank, world, sizes=None):
+    """Contiguous range [lo, hi) of rank `rank`: by packet bytes when `sizes` is given (shard_ranges), else by count."""
+    if sizes is not None:
+        first = shard_ranges(sizes, world)
+        return int(first[rank]), int(first[rank + 1])
     lo = (n_packets * rank) // world
     hi = (n_packets * (rank + 1)) // world
     return lo, hi
 
 
-def shard_batch(blob, offsets, sizes, cfg_idx, rank, world):
+def shard_batch(blob, offsets, sizes, cfg_idx, rank, world, by_bytes=False):
     """Slice a host batch down to this rank's packets (blob is shared, offsets stay absolute)."""
-    lo, hi = shard_range(len(sizes), rank, world)
+    lo, hi = shard_range(len(sizes), rank, world, sizes if by_bytes else None)
     ci = None if cfg_idx is None else np.ascontiguousarray(cfg_idx[lo:hi])
     return blob, np.ascontiguousarray(offsets[lo:hi]), np.ascontiguousarray(sizes[lo:hi]), ci, (lo, hi)
 

@@ -265,6 +265,76 @@ def measure_allgather(torch, dist, sharding, w, world, rank, dev, backend, reps=
     return alone_ms, over_ms, ok
 
 
+def measure_allgather_native(pkg, torch, dist, np, w, world, rank, dev, cdev, reps=3):
+    """The same two figures through the C ABI (alacgpu_comm_*: ncclAllGather from librccl on the caller's stream; the
+    overlapped form with its own collective stream): what a native host (the C# AlacContext) gets.  Weak scaling: every
+    rank's shard has n packets, global packet r*n + i = rank r's packet i.  Returns (alone ms, overlapped ms, ok)."""
+    n, slot = w.n_packets, w.slot
+    uid = torch.zeros(128, dtype=torch.uint8, device=cdev)
+    if rank == 0:
+        uid.copy_(torch.from_numpy(pkg.AlacGpuComm.unique_id()).to(cdev))
+    dist.broadcast(uid, src=0)
+    first = np.arange(world + 1, dtype=np.uint32) * n
+    with pkg.AlacGpuComm(w.ctx, uid.cpu().numpy(), rank, world) as comm:
+        full = torch.zeros((world * n, slot), dtype=torch.int32, device=dev)
+        stream = torch.cuda.current_stream(dev)
+        full[rank * n:(rank + 1) * n].copy_(w.d_pcm)
+        comm.allgather_pcm(full, first, slot, stream=stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            comm.allgather_pcm(full, first, slot, stream=stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        alone_ms = (time.perf_counter() - t1) / reps * 1e3
+        ok = bool(torch.equal(full[rank * n:(rank + 1) * n], w.d_pcm))
+        # every rank's shard must have arrived: compare a checksum of each shard with its owner's
+        sums = torch.stack([full[r * n:(r + 1) * n].sum(dtype=torch.int64) for r in range(world)]).to(cdev)
+        mine = sums.clone()
+        dist.broadcast(sums, src=0)
+        ok = ok and bool(torch.equal(sums, mine))
+        # overlapped: global metadata on every GPU; this rank decodes its range straight into `full`
+        def cat(t, fill=0):
+            g = torch.full((world * n,) + tuple(t.shape[1:]), fill, dtype=t.dtype, device=dev)
+            g[rank * n:(rank + 1) * n].copy_(t)
+            return g
+        g_off, g_sz = cat(w.d_off), cat(w.d_sz)
+        g_ci = None if w.d_ci is None else cat(w.d_ci)
+        g_ob, g_os, g_st = cat(w.d_ob), cat(w.d_os), cat(w.d_st, -1)
+        full.zero_()
+        run = lambda: comm.decode_allgather_device(w.d_blob, w.blob_bytes, g_off, g_sz, g_ci, first, full, slot, g_ob, g_os, g_st,
+                                                   n_chunks=4, stream=stream.cuda_stream)
+        run()
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            run()
+        torch.cuda.synchronize(dev)
+        over_ms = (time.perf_counter() - t1) / reps * 1e3
+        ok = ok and bool(torch.equal(full[rank * n:(rank + 1) * n], w.d_pcm)) and bool(torch.equal(g_st[rank * n:(rank + 1) * n], w.d_st))
+        sums2 = torch.stack([full[r * n:(r + 1) * n].sum(dtype=torch.int64) for r in range(world)]).to(cdev)
+        ok = ok and bool(torch.equal(sums2, mine))
+        del full
+    return alone_ms, over_ms, ok
+
+
+def gather_figures(pkg, torch, dist, sharding, np, w, world, rank, dev, cdev, backend):
+    """(alone ms, overlapped ms, ok, which): through the C ABI's RCCL entry points when the collective operands can stay in
+    HBM (backend nccl), through torch.distributed otherwise (gloo rehearsals) -- or when the native path fails, which the
+    line then says."""
+    if backend == "nccl":
+        try:
+            a, o, ok = measure_allgather_native(pkg, torch, dist, np, w, world, rank, dev, cdev)
+            return a, o, ok, "alacgpu_comm (C ABI, RCCL)"
+        except Exception as e:   # noqa: BLE001
+            note = f"alacgpu_comm failed ({type(e).__name__}: {e}); torch.distributed instead"[:300]
+            a, o, ok = measure_allgather(torch, dist, sharding, w, world, rank, dev, backend)
+            return a, o, ok, note
+    a, o, ok = measure_allgather(torch, dist, sharding, w, world, rank, dev, backend)
+    return a, o, ok, f"torch.distributed ({backend})"
+
+
 def main():
     argv = sys.argv[1:]
     args = parse_args(argv)
@@ -323,13 +393,15 @@ def main():
     # ---- N>1: decoded-PCM all-gather (outside the timed region) and the two multi-GPU configs of BASELINE.json ----
     allgather_ms = overlapped_ms = None
     gather_ok = True
+    gather_via = None
     extra = {}
     extra_error = None
     # (the headline measurement above is complete at this point; a failure below -- out of memory, a collective that the
     # node's fabric refuses -- is reported in the line as "extra_error" instead of taking `value` down with it)
     try:
         if distributed and not args.no_allgather:
-            allgather_ms, overlapped_ms, gather_ok = measure_allgather(torch, dist, sharding, w, world, rank, dev, args.backend)
+            allgather_ms, overlapped_ms, gather_ok, gather_via = gather_figures(pkg, torch, dist, sharding, np, w, world, rank, dev, cdev,
+                                                                                 args.backend)
         if distributed and not args.no_extra:
             for cfgno in (4, 5):
                 if cfgno == args.config:
@@ -346,7 +418,7 @@ def main():
                        "kernel_ms": round(kms, 4), "roofline_frac": round(we.algo_bytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                        "status_ok": bad == 0}
                 if not args.no_allgather:
-                    a_ms, o_ms, g_ok = measure_allgather(torch, dist, sharding, we, world, rank, dev, args.backend)
+                    a_ms, o_ms, g_ok, _ = gather_figures(pkg, torch, dist, sharding, np, we, world, rank, dev, cdev, args.backend)
                     a_ms, o_ms = reduce_max(torch, dist, cdev, a_ms, o_ms)
                     row.update(allgather_ms=round(a_ms, 4), decode_allgather_overlapped_ms=round(o_ms, 4),
                                allgather_bytes_per_rank=int(we.d_pcm.numel() * 4))
@@ -463,7 +535,7 @@ def main():
             "parity_vs_oracle": parity, "status_ok": status_ok,
             "allgather_ms": None if allgather_ms is None else round(allgather_ms, 4),
             "decode_allgather_overlapped_ms": None if overlapped_ms is None else round(overlapped_ms, 4),
-            "allgather_ok": gather_ok if distributed else None,
+            "allgather_ok": gather_ok if distributed else None, "allgather_via": gather_via,
             "gen_seconds": round(w.gen_s, 2),
         }
         if traffic_note:

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ALACGPU_VERSION 2
+#define ALACGPU_VERSION 3
 
 /* Stream configuration = the AlacFile ctor args + what AlacFile.SetInfo keeps
  * (AlacFile.cs:16-20 and :63-93; CodecData byte offsets in brackets). 12 bytes, blittable. */
@@ -59,7 +59,8 @@ enum {
     ALACGPU_ERR_NO_DEVICE = -2,          /* no usable gfx950 GPU: there is no CPU fallback */
     ALACGPU_ERR_HIP = -3,                /* a HIP runtime call failed; see alacgpu_last_error */
     ALACGPU_ERR_UNSUPPORTED_CONFIG = -4, /* a cfg is outside the kernel's domain (rice_kmodifier not in 1..16, channels not 1/2) */
-    ALACGPU_ERR_NO_MEMORY = -5
+    ALACGPU_ERR_NO_MEMORY = -5,
+    ALACGPU_ERR_COMM = -6                /* RCCL could not be loaded or a collective failed; see alacgpu_comm_last_error */
 };
 
 typedef struct alacgpu_ctx alacgpu_ctx;
@@ -106,16 +107,57 @@ int alacgpu_decode_batch(alacgpu_ctx* ctx, const uint8_t* blob, uint64_t blob_by
 
 /*
  * The same batch over SEVERAL contexts from one process -- normally one context per GPU of the node (alacgpu_device_count,
- * alacgpu_create with device = 0, 1, ...): the packets are cut into n_ctxs contiguous ranges, one host thread per
- * context runs alacgpu_decode_batch on its range, and every range writes its own part of the caller's arrays (nothing
- * to gather).  All contexts must have been created with the same cfgs and output format.  This is how a single-process
- * host (the C# AlacContext) uses every GPU of a node; the multi-process form (one rank per GPU, RCCL all-gather of the
- * PCM) is what bench.py and alac.net_amd/sharding.py do.
+ * alacgpu_create with device = 0, 1, ...): the packets are cut into n_ctxs contiguous ranges (alacgpu_shard_ranges: whole
+ * groups of 8 packets, balanced by packet bytes), one host thread per context runs alacgpu_decode_batch on its range, and
+ * every range writes its own part of the caller's arrays (nothing to gather).  All contexts must have been created with
+ * the same cfgs and output format and must be DISTINCT (a context is not thread-safe: ALACGPU_ERR_BAD_ARG otherwise).
+ * This is how a single-process host (the C# AlacContext) uses every GPU of a node with results in HOST memory; for
+ * results that stay in HBM on every GPU see alacgpu_comm_* below (one process per GPU).
  */
 int alacgpu_decode_batch_sharded(alacgpu_ctx* const* ctxs, uint32_t n_ctxs, const uint8_t* blob, uint64_t blob_bytes,
                                  const uint64_t* offsets, const uint32_t* sizes, const uint16_t* cfg_idx, uint32_t n_packets,
                                  int32_t* pcm_out, uint32_t slot_ints, int32_t* out_bytes, int32_t* out_samples,
                                  int32_t* status);
+
+/*
+ * The packet partition every multi-GPU entry point uses: contiguous ranges, cut at multiples of
+ * 8 packets, whose summed packet bytes are as equal as such cuts allow.  first[] gets world + 1 entries; rank r owns
+ * packets first[r] .. first[r+1].  Pure host arithmetic (no GPU needed).
+ */
+int alacgpu_shard_ranges(const uint32_t* sizes, uint32_t n_packets, uint32_t world, uint32_t* first);
+
+/*
+ * Multi-GPU, one process per GPU (north_star: "packet batches shard trivially across the 8 GPUs of one node with an RCCL
+ * all-gather of decoded PCM over xGMI"; there is no counterpart in the reference, whose AlacContext.cs:195-197 decodes one
+ * packet at a time on the host).  Every process makes its alacgpu_ctx, rank 0 makes an id (alacgpu_comm_get_unique_id:
+ * 128 bytes) and hands it to the others by whatever channel the host has, and all call alacgpu_comm_create (collective:
+ * ncclCommInitRank).  RCCL is loaded when the first of these functions is called (librccl.so, the copy already in the
+ * process if there is one); a host that never calls them does not need it.
+ *   alacgpu_allgather_pcm          d_full holds the WHOLE batch's slots in global packet order on this rank's GPU; this
+ *                                  rank's packets first[rank] .. first[rank+1] are decoded in place; on return (asynchronous
+ *                                  on hip_stream) every rank holds every packet: one in-place all-gather(-v) of int32
+ *   alacgpu_decode_allgather_device  decode + gather overlapped: this rank's range is decoded in n_chunks (1..4) pieces on
+ *                                  hip_stream, piece k is gathered on the communicator's own stream while piece k+1
+ *                                  decodes; hip_stream waits for the last gather.  All device arrays are indexed by
+ *                                  GLOBAL packet number (the batch's metadata is resident on every GPU).
+ * All ranks must make the same calls with the same first[] / n_chunks.  Return codes as elsewhere; ALACGPU_ERR_COMM =
+ * RCCL missing or a collective failed (alacgpu_comm_last_error(comm), or (NULL) for the calling thread's last failure).
+ */
+#define ALACGPU_COMM_ID_BYTES 128
+typedef struct alacgpu_comm alacgpu_comm;
+int alacgpu_comm_get_unique_id(void* id128);
+int alacgpu_comm_create(alacgpu_ctx* ctx, const void* id128, int rank, int world, alacgpu_comm** out_comm);
+void alacgpu_comm_destroy(alacgpu_comm* comm);
+int alacgpu_comm_rank(const alacgpu_comm* comm);
+int alacgpu_comm_world(const alacgpu_comm* comm);
+const char* alacgpu_comm_last_error(const alacgpu_comm* comm);
+int alacgpu_allgather_pcm(alacgpu_comm* comm, void* d_full_pcm, const uint32_t* first, uint32_t slot_ints, void* hip_stream);
+int alacgpu_decode_allgather_device(alacgpu_ctx* ctx, alacgpu_comm* comm, const void* d_blob, uint64_t blob_bytes,
+                                    const void* d_offsets, const void* d_sizes, const void* d_cfg_idx, const uint32_t* first,
+                                    void* d_full_pcm, uint32_t slot_ints, void* d_out_bytes, void* d_out_samples,
+                                    void* d_status, uint32_t n_chunks, void* hip_stream);
+/* the device ordinal a context was created on */
+int alacgpu_ctx_device(const alacgpu_ctx* ctx);
 
 /*
  * Same, on DEVICE buffers already resident in HBM (all pointers are device pointers), asynchronous on

@@ -25,7 +25,8 @@ def test_header_symbols_are_exported_and_bound():
     for n in names:
         assert hasattr(L, n), f"libalacgpu.so does not export {n}"
         assert n in pkg.SYMBOLS, f"python binding table misses {n}"
-    assert L.alacgpu_version() == 2
+    assert L.alacgpu_version() == 3
+    assert "alacgpu_comm_create" in names and "alacgpu_allgather_pcm" in names and "alacgpu_shard_ranges" in names
 
 
 def test_cfg_struct_layout_matches_header():
@@ -93,3 +94,27 @@ def test_product_does_not_import_the_oracle():
             if fn.endswith((".py", ".hip", ".h", ".c", ".cpp", ".hpp")):
                 txt = open(os.path.join(dirpath, fn), errors="ignore").read()
                 assert "alac_oracle" not in txt and "oracle/" not in txt, f"{fn} references the oracle"
+
+
+def test_product_kernels_carry_no_diagnostics():
+    """The product objects are compiled without ALAC_DIAG: after preprocessing, the kernel TU and the C ABI contain no clock
+    reads, no stamp pointer, no experiment switches (diagnostics live in alac_diag.h and exist in `make diag` builds only)."""
+    import subprocess
+
+    csrc = os.path.join(ROOT, "alac.net_amd", "csrc")
+    for src, emits in (("alac_kernels.hip", ("1", "2", "3", "4", "5")), ("alacgpu_api.hip", (None,)), ("alacgpu_comm.hip", (None,))):
+        for emit in emits:
+            cmd = ["/opt/rocm/bin/hipcc", "-E", "-P", "--offload-arch=gfx950", "--cuda-device-only" if emit else "--cuda-host-only",
+                   "-I", os.path.join(ROOT, "include"), "-I", csrc, os.path.join(csrc, src)]
+            if emit:
+                cmd.insert(2, f"-DALAC_EMIT={emit}")
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr[-2000:]
+            # only what comes from this repository's own sources (the HIP headers mention clock64 themselves)
+            own = r.stdout[r.stdout.rfind("namespace alacdev"):] if emit else r.stdout[r.stdout.rfind("struct alacgpu_ctx"):] if "api" in src else r.stdout[r.stdout.rfind("struct rccl_api"):]
+            assert len(own) > 2000, (src, emit)
+            for word in ("clock64", "s_memtime", "dbg", "ALAC_EXPERIMENT", "SpecStats st;\n    st."):
+                assert word not in own, f"{src} (ALAC_EMIT={emit}): `{word}` in the product translation unit"
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    product = mk[:mk.index("diag:")]
+    assert "ALAC_DIAG" not in product.replace("# ", "")or all("ALAC_DIAG" not in l for l in product.splitlines() if not l.lstrip().startswith("#"))

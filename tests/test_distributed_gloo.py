@@ -66,6 +66,53 @@ def test_two_rank_shard_and_allgather(tmp_path, n_packets):
     assert open(tmp_path / "result.txt").read() == "ok"
 
 
+def test_byte_balanced_ranges_python_and_library_agree():
+    """ranges balanced by cumulative packet bytes when packet sizes are skewed; the library's
+    alacgpu_shard_ranges (what alacgpu_decode_batch_sharded and the RCCL entry points use) and sharding.shard_ranges (what the
+    Python ranks use) are the same arithmetic."""
+    import alac.net_amd as pkg
+    from alac.net_amd import sharding, synth
+
+    b = synth.make_config_batch(5, n_packets=4096, n_threads=2)
+    rng = np.random.default_rng(11)
+    skew = b["sizes"].copy()
+    skew[:1500] = 3                                    # a long run of tiny packets in front
+    cases = [b["sizes"], skew, rng.integers(1, 70000, 999).astype(np.uint32), np.array([5, 5, 5], dtype=np.uint32),
+             np.zeros(0, dtype=np.uint32), np.full(65536, 5000, dtype=np.uint32)]
+    for sizes in cases:
+        for world in (1, 2, 3, 4, 8):
+            a = pkg.shard_ranges(sizes, world)
+            c = sharding.shard_ranges(sizes, world)
+            assert np.array_equal(a, c), (len(sizes), world, a, c)
+            assert a[0] == 0 and a[-1] == len(sizes) and np.all(np.diff(a.astype(np.int64)) >= 0)
+            assert all(int(x) % 8 == 0 or int(x) == len(sizes) for x in a[1:-1])   # whole groups of 8
+            if len(sizes) >= 4096:
+                by = [int(sizes[a[r]:a[r + 1]].astype(np.int64).sum()) for r in range(world)]
+                assert max(by) <= 1.05 * min(by), (world, by)
+    # uniform packets: equal counts (one plain all-gather)
+    a = pkg.shard_ranges(np.full(65536, 5000, dtype=np.uint32), 8)
+    assert np.array_equal(a, np.arange(9) * 8192)
+    # shard_batch by bytes hands out exactly those ranges
+    for rank in range(8):
+        _, offs, sz, ci, (lo, hi) = sharding.shard_batch(b["blob"], b["offsets"], skew, b["cfg_idx"], rank, 8, by_bytes=True)
+        f = sharding.shard_ranges(skew, 8)
+        assert (lo, hi) == (int(f[rank]), int(f[rank + 1])) and len(sz) == hi - lo
+
+
+def test_sharded_entry_rejects_the_same_context_twice():
+    """alacgpu_decode_batch_sharded: one context on two threads would race (a context is not thread-safe): checked before
+    anything touches a GPU -- needs no device, the handles are never dereferenced past the comparison."""
+    import ctypes as C
+    import alac.net_amd as pkg
+
+    L = pkg.lib()
+    fake = C.c_void_p(0x1000)
+    handles = (C.c_void_p * 2)(fake, fake)
+    # (n_ctxs == 2 with identical handles: BAD_ARG comes from the duplicate check or, without one, a crash)
+    dup = L.alacgpu_decode_batch_sharded(handles, 2, None, 0, None, None, None, 0, None, 0, None, None, None)
+    assert dup == -1
+
+
 def test_shard_ranges_cover_everything():
     from alac.net_amd import sharding
 
