@@ -413,8 +413,12 @@ class AlacFile:
                 and int(self._cfg[0]["sample_size"]) not in (20, 32)):
             return out_bytes  # a two-channel element of any other sample size: nothing is written, no exception (:701-716)
         if st == ST_UNSUPPORTED_PREDTYPE and len(inbuffer) and (int(inbuffer[0]) >> 5) == 0:
-            # one-channel element with an unknown prediction type: the reference skips the predictor silently and hands
-            # out whatever its buffer held (AlacFile.cs:484-496); here the caller's buffer is left as it was
+            # one-channel element with a prediction type other than 0: the reference skips the predictor without a word and
+            # hands out _outputsamplesBufferA (AlacFile.cs:484-496) -- which, once a compressed frame has been decoded, IS
+            # the residual buffer (:486): the un-predicted residuals, which is what the library returns with status 3.
+            # (A decoder that has never decoded a compressed frame would show zeros there: not reproduced)
+            n = min(len(outbuffer), len(ref))
+            outbuffer[:n] = ref[:n]
             return out_bytes
         self._raise_for(st)
         n = min(len(outbuffer), len(ref))

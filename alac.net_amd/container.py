@@ -372,10 +372,11 @@ class AlacContext:
             slot = 16384 * int(self._cfg[0]["num_channels"])
             pcm, ob, os_, st = self._gpu.decode_batch(blob, offsets, sizes, None, slot)
         self._currentSampleBlock += len(sizes)
-        # a one-channel element with an unknown prediction type: the reference decodes nothing and hands out its stale
-        # buffer without throwing (AlacFile.cs:484-496); here: silence of the same length (status 1 = nothing decoded)
+        # a one-channel element with a prediction type other than 0: the reference skips the predictor without throwing and
+        # hands out its output buffer, which behind any compressed frame is the residual buffer (AlacFile.cs:484-496 with
+        # :486): the library decodes exactly that (status 3 as a warning) -- an ordinary packet from here on
         first = blob[np.minimum(offsets, max(len(blob) - 1, 0)).astype(np.int64)] if len(blob) else np.zeros(len(sizes), np.uint8)
-        st = np.where((st == 3) & ((first >> 5) == 0) & (sizes > 0), 1, st).astype(np.int32)
+        st = np.where((st == 3) & ((first >> 5) == 0) & (sizes > 0), 0, st).astype(np.int32)
         # a two-channel element in a stream whose sample size is neither 16 / 24 nor 20 / 32: nothing written, no exception (:701-716)
         if int(self._cfg[0]["sample_size"]) not in (16, 24, 20, 32):
             st = np.where((st == 2) & ((first >> 5) == 1) & (sizes > 0), 1, st).astype(np.int32)
@@ -403,9 +404,9 @@ class AlacContext:
             for p in range(len(st)):
                 self._ready.append((pcm[p], int(ob[p]), int(os_[p]), int(st[p]), int(durs[p])))
         pcm, out_bytes, n, st, dur = self._ready.pop(0)
-        self.LastSampleNumber += dur                              # :199
         if st not in (0, 1):
-            self._raise_for(st)
+            self._raise_for(st)                                   # DecodeFrame throws before :198-199 count the packet
+        self.LastSampleNumber += dur                              # :199
         ref = expand_reference_layout(self._cfg, pcm, max(n, 0)) if st == 0 else np.zeros(0, dtype=np.int32)
         bps = self.GetBytesPerSample()
         out_bytes -= self._offset * bps                           # :200

@@ -281,7 +281,7 @@ __device__ __forceinline__ uint32_t ab_entropy_pass(const alac_decode_params& p,
     const int src = real ? lane : srcmax;
     RiceCfg mc;
     mc.kmod = mirror_i(rc.kmod, src);
-    mc.kmask = (1u << mc.kmod) - 1u;
+    mc.kmask = (1u << (mc.kmod & 31)) - 1u;      // (1 << kb) - 1 with C#'s five-bit shift count (AlacFile.cs:483)
     mc.hist_mult = mirror_i(rc.hist_mult, src);
     mc.rss = mirror_i(rc.rss, src);
     int n_eff = mirror_i(m.n, src);
@@ -336,7 +336,7 @@ __device__ __forceinline__ uint32_t ab_entropy_pass(const alac_decode_params& p,
                 rs.zrun = mirror_i(rs.zrun, s2);
                 rs.nforce = (uint32_t)mirror_i((int)rs.nforce, s2);
                 mc.kmod = mirror_i(mc.kmod, s2);
-                mc.kmask = (1u << mc.kmod) - 1u;
+                mc.kmask = (1u << (mc.kmod & 31)) - 1u;
                 mc.hist_mult = mirror_i(mc.hist_mult, s2);
                 mc.rss = mirror_i(mc.rss, s2);
                 mring = (uint32_t)mirror_i((int)mring, s2);
@@ -434,7 +434,7 @@ __device__ __forceinline__ void ab_entropy_wave(const alac_decode_params& p, uin
     const bool compressed = valid && m.status == 0 && !m.esc;
     RiceCfg rc;
     rc.kmod = cfg.rice_kmodifier;
-    rc.kmask = (1u << cfg.rice_kmodifier) - 1u;
+    rc.kmask = (1u << (cfg.rice_kmodifier & 31)) - 1u;
     rc.hist_mult = m.ricemod * (cfg.rice_history_mult / 4);
     rc.rss = m.rss;
     int flags_a = 0, flags_b = 0;
@@ -513,31 +513,37 @@ __device__ __forceinline__ void ab_fir_wave(const alac_decode_params& p, uint32_
     const Meta m = parse_meta(p, pkt, ph, valid, cfg);
     const bool stream_on = valid && m.status == 0 && !m.esc && (ph == 0 || m.stereo);
     const int n_row = stream_on ? m.n : 0;
-    const bool gen = stream_on && m.N >= 1 && m.N <= 30;     // the general mode (:297-334)
+    // A one-channel element with a prediction type other than 0: the reference skips the predictor without a word and hands
+    // out _outputsamplesBufferA (AlacFile.cs:484-496) -- which, once any compressed frame has been decoded, IS the residual
+    // buffer (:486: the predictor returns its input array): the un-predicted residuals come out.  Reproduced as order 0;
+    // the status (3) stays as a warning.  (A two-channel element throws, :650/:660: status 3, output unspecified.)
+    const bool unpredicted = stream_on && !m.stereo && m.predtype != 0;
+    const int N = unpredicted ? 0 : m.N;
+    const bool gen = stream_on && N >= 1 && N <= 30;         // the general mode (:297-334)
     FirB<T> f;
     f.q = stream_on ? m.q : 1;
     f.rss = stream_on ? m.rss : 16;
     f.qmask = (1 << f.q) - 1;
     f.bias = 1 << (f.rss - 1);
-    f.N = stream_on ? m.N : 0;
-    f.n0 = stream_on && m.N == 0;
-    f.delta = stream_on && m.N == 31;
+    f.N = stream_on ? N : 0;
+    f.n0 = stream_on && N == 0;
+    f.delta = stream_on && N == 31;
     f.rnd0 = (gen && jl == 0) ? m.rnd : 0;
     f.base = f.prev = f.bias;
     int oidx[T];           // where this lane's registers go in the output queue: tap t < 8 -> the lane 2 t + par of the row
 #pragma unroll
     for (int r = 0; r < T; r++) {
         const int t = T * jl + r;
-        const bool tap = gen && t < m.N;
+        const bool tap = gen && t < N;
         f.h[r] = f.bias;
         f.c[r] = tap ? (int)(int16_t)peek_bits(m.base, m.limit, m.coefbit + 16u * t, 16) : 0;   // :466-475
         f.tlo[r] = tap ? -1 : 0;
         f.thi[r] = tap ? 1 : 0;
-        f.w[r] = tap ? (uint32_t)(m.N - t) : 0u;
+        f.w[r] = tap ? (uint32_t)(N - t) : 0u;
         oidx[r] = 64 * w + (lane & 48) + 2 * (t & 7) + par;
     }
     const bool writer = T * jl < 8;     // this lane holds taps below 8: the newest 8 samples after every 8 steps
-    const int tl = gen ? m.N - 1 : 0;
+    const int tl = gen ? N - 1 : 0;
     f.bpaddr = ((lane & 48) + 2 * (tl / T) + par) * 4;
     f.bsel = tl % T;
     const int nmax = __builtin_amdgcn_readfirstlane(wave_max(n_row));
@@ -842,7 +848,7 @@ __device__ __forceinline__ void ab_kernel_body(const alac_decode_params& p, AbSh
         n0 = ok ? ma.n : 0;
         n1 = (ok && !ma.esc && ma.stereo) ? ma.n : 0;
         // one / two taps per lane take LPC orders 1..16; four taps per lane every order (0 and 31 as modes of the step)
-        bad = TSEL < 4 && ok && !ma.esc && (ma.N < 1 || ma.N > 16 || (ma.stereo && (mb.N < 1 || mb.N > 16)));
+        bad = TSEL < 4 && ok && !ma.esc && (ma.N < 1 || ma.N > 16 || (ma.stereo && (mb.N < 1 || mb.N > 16)) || (!ma.stereo && ma.predtype != 0));
         two_lane = ok && !ma.esc && (ma.N > 8 || (ma.stereo && mb.N > 8));
         wide_lane = ok && !ma.esc && ma.rss > 23;
         // the parking place needs two ints per sample in the slot (parse_meta turns anything else into a status)

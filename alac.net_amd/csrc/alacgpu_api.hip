@@ -241,7 +241,9 @@ int alacgpu_create(const alacgpu_cfg* cfgs, uint32_t n_cfgs, int device, alacgpu
     if (!cfgs || n_cfgs == 0 || !out) return ALACGPU_ERR_BAD_ARG;
     *out = nullptr;
     for (uint32_t i = 0; i < n_cfgs; i++) {
-        if (cfgs[i].rice_kmodifier < 1 || cfgs[i].rice_kmodifier > 16) return ALACGPU_ERR_UNSUPPORTED_CONFIG;
+        // (any kb SetInfo takes, AlacFile.cs:82, but 0: a value's k never exceeds 16 -- the history is bounded --, so kb > 16
+        // only changes the run-length mask (1 << kb) - 1, with C#'s shift count masked to five bits)
+        if (cfgs[i].rice_kmodifier < 1) return ALACGPU_ERR_UNSUPPORTED_CONFIG;
         if (cfgs[i].num_channels < 1 || cfgs[i].num_channels > 2) return ALACGPU_ERR_UNSUPPORTED_CONFIG;
     }
     int ndev = 0;
@@ -541,7 +543,9 @@ int alacgpu_decode_frame(alacgpu_ctx* ctx, uint32_t cfg_index, const uint8_t* in
     if (rc == ALACGPU_OK) {
         *status = st;
         if (out_bytes) *out_bytes = ob;
-        if (st == ALACGPU_ST_OK) {
+        // (a one-channel element with a prediction type other than 0 carries status 3 AND the reference's output: the
+        // un-predicted residuals, AlacFile.cs:484-496 with :486)
+        if (st == ALACGPU_ST_OK || (st == ALACGPU_ST_UNSUPPORTED_PREDTYPE && in_bytes > 0 && (inbuffer[0] >> 5) == 0)) {
             const size_t need = (size_t)os * cfg.num_channels * (cfg.sample_size == 24 ? 3 : 1);
             if (need > out_capacity_ints) rc = ALACGPU_ERR_BAD_ARG;
             else alacgpu_expand_reference_layout(&cfg, pcm, os, outbuffer);

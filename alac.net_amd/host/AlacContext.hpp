@@ -299,9 +299,10 @@ public:
             for (int p = 0; p < n; p++) {
                 Packet pk;
                 pk.outBytes = ob[(size_t)p]; pk.samples = os[(size_t)p]; pk.status = st[(size_t)p]; pk.duration = durs[(size_t)p];
-                // a one-channel element with an unknown prediction type: the reference decodes nothing and hands out its
-                // stale buffer without throwing (AlacFile.cs:484-496); here: silence of the same length
-                if (pk.status == ALACGPU_ST_UNSUPPORTED_PREDTYPE && firstByte_[(size_t)p] >> 5 == 0) pk.status = ALACGPU_ST_UNSUPPORTED_ELEMENT;
+                // a one-channel element with a prediction type other than 0: the reference skips the predictor without throwing
+                // and hands out its output buffer -- behind any compressed frame the residual buffer (AlacFile.cs:484-496 with
+                // :486); the library decodes exactly that: an ordinary packet from here on
+                if (pk.status == ALACGPU_ST_UNSUPPORTED_PREDTYPE && firstByte_[(size_t)p] >> 5 == 0) pk.status = ALACGPU_ST_OK;
                 // a two-channel element of a sample size other than 16 / 24 and 20 / 32: nothing written, no exception (:701-716)
                 if (pk.status == ALACGPU_ST_UNSUPPORTED_SAMPLE_SIZE && firstByte_[(size_t)p] >> 5 == 1 && cfg_.sample_size != 20 &&
                     cfg_.sample_size != 32)
@@ -313,8 +314,8 @@ public:
         }
         Packet pk = std::move(ready_.front());
         ready_.pop_front();
+        ThrowFor(pk.status);                                             // DecodeFrame throws before :198-199 count the packet
         LastSampleNumber += pk.duration;                                 // :199
-        ThrowFor(pk.status);
         std::vector<int32_t> ref(pk.pcm.size() * (cfg_.sample_size == 24 ? 3 : 1) + 8, 0);
         size_t refInts = pk.pcm.empty() ? 0 : alacgpu_expand_reference_layout(&cfg_, pk.pcm.data(), pk.samples, ref.data());
         const int bps = GetBytesPerSample();

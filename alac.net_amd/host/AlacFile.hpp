@@ -41,8 +41,9 @@ public:
         int32_t out_bytes = 0, status = 0;
         int rc = alacgpu_decode_frame(ctx_, 0, inbuffer, in_bytes, outbuffer, out_capacity, &out_bytes, &status);
         if (rc != ALACGPU_OK) throw std::runtime_error(std::string("alacgpu_decode_frame: ") + alacgpu_strerror(rc));
-        // a one-channel element with an unknown prediction type: the reference skips the predictor silently and hands out
-        // whatever its buffer held (AlacFile.cs:484-496); here the caller's buffer is left as it was
+        // a one-channel element with a prediction type other than 0: the reference skips the predictor without a word and hands
+        // out its output buffer, which behind any compressed frame is the residual buffer (AlacFile.cs:484-496 with :486): the
+        // library has written exactly that (the un-predicted residuals) into outbuffer, with status 3 as a warning
         if (status == ALACGPU_ST_UNSUPPORTED_PREDTYPE && in_bytes > 0 && (inbuffer[0] >> 5) == 0) return out_bytes;
         // a two-channel element of a sample size other than 16 / 24 (decoded) and 20 / 32 (throw): nothing written (:701-716)
         if (status == ALACGPU_ST_UNSUPPORTED_SAMPLE_SIZE && in_bytes > 0 && (inbuffer[0] >> 5) == 1 && cfg_.sample_size != 20 &&

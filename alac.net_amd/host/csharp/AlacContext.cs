@@ -185,15 +185,19 @@ namespace ALACdotNET.Decoder
         {
             if (_batchNext >= _batchCount && ReadBatch(BatchPackets) == 0) return 0;
             int p = _batchNext++;
-            LastSampleNumber += _durations[p];                            // :199
             int status = _status[p];
-            // one-channel element with an unknown prediction type: the reference decodes nothing and hands out its stale
-            // buffer (AlacFile.cs:484-496); here: silence of the same length
+            // one-channel element with a prediction type other than 0: the reference skips the predictor without throwing and
+            // hands out its output buffer -- behind any compressed frame the residual buffer (AlacFile.cs:484-496 with :486);
+            // the library decoded exactly that (status 3 as a warning): an ordinary packet from here on
             bool staleMono = status == AlacGpuNative.StUnsupportedPredType && (_blob[(long)_offsets[p]] >> 5) == 0;
             // a two-channel element of a sample size other than 16 / 24 and 20 / 32: nothing written, no exception (AlacFile.cs:701-716)
             bool silentStereo = status == AlacGpuNative.StUnsupportedSampleSize && (_blob[(long)_offsets[p]] >> 5) == 1 &&
                                 _alac.Config.SampleSize != 20 && _alac.Config.SampleSize != 32;
+            // (the reference's DecodeFrame throws BEFORE :198-199 count the packet: LastSampleNumber does not move for a packet
+            // that throws.  The packet itself is consumed -- the reference's stream has read past it as well, :195)
             if (!staleMono && !silentStereo) _alac.ThrowFor(status);
+            if (staleMono) status = AlacGpuNative.StOk;
+            LastSampleNumber += _durations[p];                            // :199
             int bps = GetBytesPerSample();
             int outputBytes = _outBytes[p] - _offset * bps;               // :200
             // :201 drops _offset INTS of the reference's buffer: 16-bit streams hold a sample per int (2 bytes each),
@@ -210,7 +214,7 @@ namespace ALACdotNET.Decoder
             }
             else
             {
-                Array.Clear(buffer, 0, outputBytes);                      // nothing was decoded (:437,:577 / stale mono)
+                Array.Clear(buffer, 0, outputBytes);                      // nothing was decoded (:437,:577)
             }
             return outputBytes;
         }

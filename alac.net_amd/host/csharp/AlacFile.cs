@@ -37,8 +37,9 @@ namespace ALACdotNET.Decoder
         public int DecodeFrame(byte[] inbuffer, int packetBytes, int[] outbuffer)
         {
             Check(AlacGpuNative.alacgpu_decode_frame(_ctx, 0, inbuffer, (uint)packetBytes, outbuffer, (uint)outbuffer.Length, out int outBytes, out int status));
-            // a one-channel element with an unknown prediction type: the reference skips the predictor silently and hands
-            // out whatever its buffer held (AlacFile.cs:484-496); here the caller's buffer is left as it was
+            // a one-channel element with a prediction type other than 0: the reference skips the predictor without a word and
+            // hands out its output buffer, which behind any compressed frame is the residual buffer (AlacFile.cs:484-496 with
+            // :486): alacgpu_decode_frame has written exactly that into outbuffer (status 3 is a warning here)
             if (status == AlacGpuNative.StUnsupportedPredType && (inbuffer[0] >> 5) == 0) return outBytes;
             // a two-channel element of a sample size other than 16 / 24 (decoded) and 20 / 32 (throw): nothing is written (:701-716)
             if (status == AlacGpuNative.StUnsupportedSampleSize && (inbuffer[0] >> 5) == 1 && _cfg.SampleSize != 20 && _cfg.SampleSize != 32)

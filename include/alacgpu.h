@@ -34,7 +34,7 @@ typedef struct {
     uint8_t  sample_size;           /* [29]            AlacFile.cs:76  (16 or 24 decode; others -> status) */
     uint8_t  rice_history_mult;     /* [30]            AlacFile.cs:78  */
     uint8_t  rice_initial_history;  /* [31]            AlacFile.cs:80  */
-    uint8_t  rice_kmodifier;        /* [32]            AlacFile.cs:82  (1..16 supported) */
+    uint8_t  rice_kmodifier;        /* [32]            AlacFile.cs:82  (1..255; 0 is refused) */
     uint8_t  num_channels;          /* ctor arg,       AlacFile.cs:18  (1 or 2) */
     uint8_t  ctor_sample_size;      /* ctor arg samplesize (AlacFile.cs:19); 0 = same as sample_size */
     uint8_t  reserved;
@@ -58,7 +58,7 @@ enum {
     ALACGPU_ERR_BAD_ARG = -1,
     ALACGPU_ERR_NO_DEVICE = -2,          /* no usable gfx950 GPU: there is no CPU fallback */
     ALACGPU_ERR_HIP = -3,                /* a HIP runtime call failed; see alacgpu_last_error */
-    ALACGPU_ERR_UNSUPPORTED_CONFIG = -4, /* a cfg is outside the kernel's domain (rice_kmodifier not in 1..16, channels not 1/2) */
+    ALACGPU_ERR_UNSUPPORTED_CONFIG = -4, /* a cfg is outside the kernel's domain (rice_kmodifier 0, channels not 1/2) */
     ALACGPU_ERR_NO_MEMORY = -5,
     ALACGPU_ERR_COMM = -6                /* RCCL could not be loaded or a collective failed; see alacgpu_comm_last_error */
 };

@@ -79,7 +79,7 @@ def test_create_rejects_unsupported_config():
     import alac.net_amd as pkg
 
     L = pkg.lib()
-    cfgs = pkg.make_cfgs([(4096, 16, 40, 10, 20, 2)])  # rice_kmodifier 20 is outside 1..16
+    cfgs = pkg.make_cfgs([(4096, 16, 40, 10, 0, 2)])  # rice_kmodifier 0 (any other byte is taken, as by SetInfo, AlacFile.cs:82)
     ctx = ctypes.c_void_p()
     rc = L.alacgpu_create(cfgs.ctypes.data_as(ctypes.c_void_p), 1, 0, ctypes.byref(ctx))
     assert rc == -4 and not ctx

@@ -188,6 +188,30 @@ def test_exotic_stream_configs(pkg, oracle, synth):
     assert_same(g, o, cfgs, ci)
 
 
+def test_rice_kmodifier_beyond_sixteen(pkg, oracle, synth):
+    # AlacFile.cs:82 takes any byte: a value's k is bounded by the history (<= 16), so kb > 16 only changes the run-length
+    # mask (1 << kb) - 1 -- with C#'s shift count masked to five bits (kb 40 -> 0xFF, kb 33 -> 1)
+    cfgs = [(4096, 16, 40, 10, 17, 2), (4096, 16, 40, 10, 24, 2), (4096, 16, 40, 10, 33, 2), (4096, 24, 40, 10, 40, 2), (4096, 16, 40, 10, 255, 1)]
+    d = synth.packet_descs(80, n=900, max_samples_per_frame=4096)
+    ci = (np.arange(80) % 5).astype(np.uint16)
+    for j, c in enumerate(cfgs):
+        m = ci == j
+        d['sample_size'][m] = c[1]
+        d['rice_kmodifier'][m] = c[4]
+        d['stereo'][m] = 1 if c[5] == 2 else 0
+    sig = synth.default_signal(17)
+    sig['silence_prob'] = 0.8                      # zero runs: the symbols the mask touches
+    sig['silence_min'], sig['silence_max'] = 8, 400
+    b = synth.make_batch(d, sig, want_pcm=True)
+    b.update(stream_cfgs=cfgs, cfg_idx=ci)
+    g, o = run_both(pkg, oracle, b)
+    assert (o[3] == 0).all()
+    assert_same(g, o, cfgs, ci)
+    for p in range(80):
+        cnt = int(d['n'][p]) * cfgs[int(ci[p])][5]
+        assert np.array_equal(g[0][p, :cnt], b['pcm'][p, :cnt])
+
+
 def test_mutated_packets_never_hang_and_match(pkg, oracle, synth):
     # flip bits in valid packets; every packet is followed by zero padding so that both decoders see
     # zeros past a (possibly now too short) packet.  The kernel must terminate and agree with the oracle
@@ -579,9 +603,10 @@ def test_hand_kats_round2_on_gpu(pkg):
     assert pcm[0, :1].tolist() == [103] and pcm[1, :2].tolist() == [1, 32767]
 
 
-def test_mono_element_with_unknown_prediction_type_does_not_throw(pkg, synth):
-    # AlacFile.cs:484-496: a one-channel element whose predictionType is not 0 skips the predictor silently (the output is
-    # stale scratch); a two-channel element throws (:650,:660).  The host mirrors reproduce the difference.
+def test_mono_element_with_unknown_prediction_type_does_not_throw(pkg, oracle, synth):
+    # AlacFile.cs:484-496: a one-channel element whose predictionType is not 0 skips the predictor silently and the output
+    # buffer comes out as it is -- behind any compressed frame that is the residual buffer (:486), i.e. the un-predicted
+    # residuals; a two-channel element throws (:650,:660).  The host mirrors reproduce the difference.
     d = synth.packet_descs(2, n=64, max_samples_per_frame=4096, stereo=0)
     d["pred_type"][0] = [2, 0]
     d["stereo"][1] = 1
@@ -592,7 +617,10 @@ def test_mono_element_with_unknown_prediction_type_does_not_throw(pkg, synth):
     f = pkg.AlacFile(16, 2)
     f.SetInfo(cd)
     out = np.full(1024 * 80, 7, dtype=np.int32)
-    assert f.DecodeFrame(pk[0], out) == 64 * 4 and (out == 7).all()      # returns outputsize, buffer untouched
+    assert f.DecodeFrame(pk[0], out) == 64 * 4                           # returns outputsize, no exception
+    ref = oracle.decode_batch(oracle.make_cfgs([(4096, 16, 40, 10, 14, 2)]), b["blob"], b["offsets"][:1], b["sizes"][:1], None, 8192)
+    assert ref[3][0] == 3 and np.array_equal(out[:128], ref[0][0, :128])   # the residuals (L), 0 (R)
+    assert len(set(out[0:128:2].tolist())) > 8                           # ... which are not silence
     with pytest.raises(Exception, match="unhandled predicition type"):
         f.DecodeFrame(pk[1], out)
     f.Dispose()
