@@ -583,12 +583,13 @@ template <int T, bool WIDE, bool SPECIAL, int PH, typename E>
 __device__ __forceinline__ void firb_step(FirB<T>& f, const E e) {
     constexpr bool SHORT = sizeof(E) == sizeof(XQ8);
     XQ x;
+    int smask = 0;
     if constexpr (SHORT) {
         x.err = e.err;
         x.mag = e.mag;
-        const int s = e.err >> 31;
-        x.rq = s & f.qmask;
-        x.sgn = s | 1;
+        smask = e.err >> 31;
+        x.rq = smask & f.qmask;
+        x.sgn = 0;
     } else {
         x = e;
     }
@@ -626,9 +627,16 @@ __device__ __forceinline__ void firb_step(FirB<T>& f, const E e) {
 #pragma unroll
         for (int r = T - 1; r >= 0; r--) { visit[r] = x.mag > run; run += cc[r]; }
     }
-    // coef -= sign, sign = +-sgn(base - hist) (:325-327): the select sits on the median, the sign rides on the multiply-add
+    // coef -= sign, sign = +-sgn(base - hist) (:325-327): the select sits on the median.  With the sign +-1 at hand it rides on
+    // one multiply-add; the short queue entry only has the sign MASK s: coef + ((sd ^ s) - s) = ((sd ^ s) + (coef - s)), two
+    // full-rate instructions (the 24-bit multiply-add issues at half rate once the SIMD is saturated -- which is where the
+    // short form is used)
 #pragma unroll
-    for (int r = 0; r < T; r++) f.c[r] = mad_i24(visit[r] ? sd[r] : 0, x.sgn, f.c[r]);
+    for (int r = 0; r < T; r++) {
+        const int sdv = visit[r] ? sd[r] : 0;
+        if (SHORT) f.c[r] = xad_u32(sdv, smask, wsub(f.c[r], smask));
+        else f.c[r] = mad_i24(sdv, x.sgn, f.c[r]);
+    }
     f.h[PL] = __builtin_amdgcn_update_dpp(out, f.h[PL], DPP_ROW_SHR2, 0xF, 0xF, false);
     f.base = (SPECIAL && f.delta) ? out : nb;
 }
