@@ -608,8 +608,8 @@ __device__ __forceinline__ void firb_step(FirB<T>& f, const E e) {
         if (!WIDE) p = mad_i24(d[r], f.c[r], r == 0 ? f.rnd0 : p);
         else p = wadd(wmul(d[r], f.c[r]), r == 0 ? f.rnd0 : p);
         const uint32_t aq = sad_u32((uint32_t)hr, (uint32_t)f.base, (uint32_t)x.rq) >> f.q;
-        cc[r] = aq * f.w[r];                                                  // what the tap takes off |err| (:329)
-        if (WIDE) cc[r] = min(cc[r], 1u << 26);                               // decisions unchanged: |err| < 2^26
+        cc[r] = aq * f.w[r];                                                  // what the tap takes off |err| (:329); < 2^31
+        if (WIDE && T == 1) cc[r] = min(cc[r], 1u << 26);                     // keeps the scan from wrapping; decisions unchanged: |err| < 2^26
         sd[r] = med3_i32(d[r], f.tlo[r], f.thi[r]);                           // sign(hist - base) on tap lanes
     }
     const int sum = firb_allreduce(p);
@@ -619,13 +619,23 @@ __device__ __forceinline__ void firb_step(FirB<T>& f, const E e) {
     bool visit[T];
     if (T == 1) {
         visit[0] = x.mag + cc[0] > firb_suffix(cc[0]);
-    } else {
+    } else if (!WIDE) {
         uint32_t tot = cc[0];
 #pragma unroll
         for (int r = 1; r < T; r++) tot += cc[r];
         uint32_t run = firb_suffix(tot) - tot;                                // the lanes above
 #pragma unroll
         for (int r = T - 1; r >= 0; r--) { visit[r] = x.mag > run; run += cc[r]; }
+    } else {
+        // wide streams: the decrements can be large enough to wrap a 32-bit sum of 32 of them.  Saturating adds inside the lane
+        // and ONE clamp of the lane total (instead of one per tap) keep every partial sum either exact or above any |err|
+        uint32_t tot = cc[0];
+#pragma unroll
+        for (int r = 1; r < T; r++) tot = __builtin_elementwise_add_sat(tot, cc[r]);
+        tot = min(tot, 1u << 28);
+        uint32_t run = firb_suffix(tot) - tot;                                // <= 7 x 2^28
+#pragma unroll
+        for (int r = T - 1; r >= 0; r--) { visit[r] = x.mag > run; run = __builtin_elementwise_add_sat(run, cc[r]); }
     }
     // coef -= sign, sign = +-sgn(base - hist) (:325-327): the select sits on the median.  With the sign +-1 at hand it rides on
     // one multiply-add; the short queue entry only has the sign MASK s: coef + ((sd ^ s) - s) = ((sd ^ s) + (coef - s)), two

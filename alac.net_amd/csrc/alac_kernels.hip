@@ -237,7 +237,8 @@ struct AbSharedT {
     int resq[2][AB_CHUNK][NS];           // entropy wave -> output wave: the unsigned Rice code values dv
     Xq xq[2][AB_CHUNK][NS + 1];          // output wave -> FIR waves; column NS is never written and stays zero: what a
                                          // switched-off or finished stream is fed
-    int outq[2][AB_CHUNK / 8][NS * 8];   // FIR wave w -> output wave (lanes 64 w ..), 8 outputs per stream per 8 samples
+    int outq[2][AB_CHUNK / 8][NS * 8 + 64];   // FIR wave w -> output wave (lanes 64 w ..), 8 outputs per stream per 8 samples; the 64
+                                              // ints behind them: where FIR lanes that hold no tap below 8 write (no branch around a store)
     int dummy[AB_CHUNK * NS + 64];       // where the entropy wave's lanes without a stream of their own write
     uint32_t ring_next[NS];    // entropy wave -> output wave: Rice::next of the stream at the last barrier
     uint32_t ring_filled[NS];  // entropy wave -> output wave at the start of a pass: bytes staged by rice_init
@@ -484,7 +485,7 @@ __device__ __forceinline__ void ab_entropy_wave(const alac_decode_params& p, uin
 // The 32 steady-state steps of a chunk as one straight-line block (a lone wave pays for every block boundary); I = step
 // number inside the chunk, I % T = the register rotation phase (0 again at every multiple of 8).
 template <int T, bool WIDE, bool SPECIAL, int NS, int I>
-__device__ __forceinline__ void ab_fir_block(FirB<T>& f, const typename XqSel<NS>::type* q, typename XqSel<NS>::type x, int* oq, bool writer,
+__device__ __forceinline__ void ab_fir_block(FirB<T>& f, const typename XqSel<NS>::type* q, typename XqSel<NS>::type x, int* oq,
                                              const int (&oidx)[T]) {
     if constexpr (I < AB_CHUNK) {
         // the next step's residual is fetched one step ahead (an LDS read takes a good hundred cycles to come back)
@@ -492,10 +493,9 @@ __device__ __forceinline__ void ab_fir_block(FirB<T>& f, const typename XqSel<NS
         firb_step<T, WIDE, SPECIAL, I % T>(f, x);
         if constexpr ((I & 7) == 7) {
 #pragma unroll
-            for (int r = 0; r < T; r++)
-                if (T == 1 || writer) oq[(I >> 3) * (NS * 8) + oidx[r]] = f.h[r];
+            for (int r = 0; r < T; r++) oq[(I >> 3) * (NS * 8 + 64) + oidx[r]] = f.h[r];
         }
-        ab_fir_block<T, WIDE, SPECIAL, NS, I + 1>(f, q, xn, oq, writer, oidx);
+        ab_fir_block<T, WIDE, SPECIAL, NS, I + 1>(f, q, xn, oq, oidx);
     }
 }
 
@@ -540,9 +540,9 @@ __device__ __forceinline__ void ab_fir_wave(const alac_decode_params& p, uint32_
         f.tlo[r] = tap ? -1 : 0;
         f.thi[r] = tap ? 1 : 0;
         f.w[r] = tap ? (uint32_t)(N - t) : 0u;
-        oidx[r] = 64 * w + (lane & 48) + 2 * (t & 7) + par;
+        // tap t < 8 -> the lane 2 t + par of the row (what the output wave's lane wants); the others: the spare ints behind
+        oidx[r] = t < 8 ? 64 * w + (lane & 48) + 2 * t + par : NS * 8 + lane;
     }
-    const bool writer = T * jl < 8;     // this lane holds taps below 8: the newest 8 samples after every 8 steps
     const int tl = gen ? N - 1 : 0;
     f.bpaddr = ((lane & 48) + 2 * (tl / T) + par) * 4;
     f.bsel = tl % T;
@@ -564,7 +564,7 @@ __device__ __forceinline__ void ab_fir_wave(const alac_decode_params& p, uint32_
         if (__builtin_expect(c >= c_fast, 0))
             fast = fast && i0 + AB_CHUNK <= nmax && __builtin_amdgcn_ballot_w64(i0 < n_row && i0 + AB_CHUNK > n_row) == 0;
         if (__builtin_expect(fast, 1)) {
-            ab_fir_block<T, WIDE, SPECIAL, NS, 0>(f, q, q[0], oq, writer, oidx);
+            ab_fir_block<T, WIDE, SPECIAL, NS, 0>(f, q, q[0], oq, oidx);
             continue;
         }
 #pragma unroll 1
@@ -578,8 +578,7 @@ __device__ __forceinline__ void ab_fir_wave(const alac_decode_params& p, uint32_
                 }
             }
 #pragma unroll
-            for (int r = 0; r < T; r++)
-                if (T == 1 || writer) oq[half * (NS * 8) + oidx[r]] = f.h[r];
+            for (int r = 0; r < T; r++) oq[half * (NS * 8 + 64) + oidx[r]] = f.h[r];
         }
     }
     wg_sync();  // final barrier of the pass

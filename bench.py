@@ -138,6 +138,7 @@ class Workload:
         nch = 1 + descs["stereo"].astype(np.int64)
         self.nch = nch
         self.samples = int((descs["n"].astype(np.int64) * nch).sum())          # S_ch = sum n*channels
+        self.frames = int(descs["n"].astype(np.int64).sum())                    # S_fr = sum n (sample frames)
         ci = np.zeros(n_packets, dtype=int) if b["cfg_idx"] is None else b["cfg_idx"].astype(int)
         out_nc = np.array([b["stream_cfgs"][int(i)][5] for i in ci], dtype=np.int64)
         self.algo_bytes = int(b["sizes"].astype(np.int64).sum() + (4 * descs["n"].astype(np.int64) * out_nc).sum())
@@ -455,9 +456,13 @@ def main():
         cpuall_s = time.perf_counter() - t1
         got = w.d_pcm.cpu().numpy()
         st = w.d_st.cpu().numpy()
-        okm = refall[3] == 0
-        parity = bool(np.array_equal(st, refall[3]) and np.array_equal(got[okm], refall[0][okm])
-                      and np.array_equal(w.d_ob.cpu().numpy(), refall[1]))
+        # every packet's own n * channels ints (what a slot holds beyond them is scratch by contract, include/alacgpu.h)
+        ci_h = np.zeros(n_packets, dtype=np.int64) if b["cfg_idx"] is None else b["cfg_idx"].astype(np.int64)
+        nc_h = np.array([int(c[5]) for c in b["stream_cfgs"]], dtype=np.int64)[ci_h]
+        cnt_h = np.where(refall[3] == 0, refall[2].astype(np.int64) * nc_h, 0)
+        mask = np.arange(w.slot, dtype=np.int64)[None, :] < cnt_h[:, None]
+        parity = bool(np.array_equal(st, refall[3]) and np.array_equal(got[mask], refall[0][mask])
+                      and np.array_equal(w.d_ob.cpu().numpy(), refall[1]) and np.array_equal(w.d_os.cpu().numpy(), refall[2]))
         # single thread, pinned to one core, the same batch over and over for >= --cpu-seconds
         os.sched_setaffinity(0, {allcores[len(allcores) // 2]})
         try:
@@ -500,21 +505,30 @@ def main():
         first = ("alac_decode_ab_small_kernel" if n_packets <= 4096 else "alac_decode_ab_kernel" if n_packets <= 10240
                  else "alac_decode_ab5_kernel" if n_packets <= 12288 else "alac_decode_ab_dense_kernel")
         kernel_name = first
-        if args.config == 3:
-            # LPC order 16: two taps per lane of the FIR wave -- the main kernel's code, compiled into the second launch
-            kernel_name = f"alac_decode_ab32_kernel (the main kernel's two-taps-per-lane code; behind {first})"
+        if args.config == 3 and first != "alac_decode_ab_dense_kernel":
+            # LPC order 16: two taps per lane of the FIR wave: the second launch (the dense arrangement keeps such groups)
+            kernel_name = f"alac_decode_ab32_kernel (two taps per lane; behind {first})"
         if args.config == 5:
-            # LPC orders above 16 in (nearly) every group of 8 packets: the work is done by the 32-tap arrangement launched
-            # behind the main two-pass kernel
-            kernel_name = f"alac_decode_ab32_kernel (behind {first})"
+            # LPC orders above 16 in (nearly) every group of 8 packets: four taps per lane, the second launch
+            kernel_name = f"alac_decode_ab32_kernel (four taps per lane; behind {first})"
         # HBM traffic comes from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read in-process): the committed
         # measurement of the same workload, valid only for the kernel sources it was taken with
-        traffic, traffic_note = None, None
+        traffic, traffic_note, issue = None, None, None
         tfile = os.path.join(ROOT, "profiles", f"traffic_cfg{args.config}.json")
         if os.path.exists(tfile) and args.packets is None:
             tj = json.load(open(tfile))
             if tj.get("kernel_source_sha") == kernel_source_sha():
                 traffic = tj["hbm_bytes_per_launch"]
+                # the issue-rate ceiling that makes the HBM fraction interpretable.  The kernels are bound
+                # by VALU issue (a SIMD issues one wave64 VALU instruction per 4 cycles), not by bandwidth: ceiling = SIMDs x clock
+                # / 4 / (VALU wave-instructions per sample, from the committed SQ_INSTS_VALU pass of this very workload)
+                if tj.get("valu_wave_instr_per_launch"):
+                    ips = tj["valu_wave_instr_per_launch"] / w.samples
+                    simds, clock = 1024, float(tj.get("effective_clock_GHz") or 2.4)
+                    ceiling = simds * clock * 1e3 / 4.0 / ips          # Msamples/s
+                    issue = {"valu_wave_instr_per_sample": round(ips, 3), "simd_count": simds, "clock_ghz": round(clock, 3),
+                             "cycles_per_wave_instr": 4, "ceiling_msamples": round(ceiling, 1),
+                             "source": tj.get("source")}
             else:
                 traffic_note = "profiles/traffic_cfg%d.json was measured with other kernel sources (stale): not reported" % args.config
         ms_per_step = elapsed / args.steps * 1e3
@@ -527,6 +541,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": NAMES[args.config], "packets_per_gpu": n_packets,
                        "samples_per_step_per_gpu": w.samples, "parallelism": f"packet-sharded x{world}"},
+            "value_frames": round(value * w.frames / w.samples, 3),    # S_fr: sample frames per second
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "kernel": kernel_name, "kernel_ms": round(kernel_ms, 4),
@@ -540,6 +555,10 @@ def main():
         }
         if traffic_note:
             line["roofline"]["traffic_note"] = traffic_note
+        if issue:
+            # per GPU, kernel time only (like `frac`): what the decode itself reaches of the chip's VALU issue rate
+            issue["frac_of_issue_ceiling"] = round(w.samples / (kernel_ms * 1e-3) / 1e6 / issue["ceiling_msamples"], 4)
+            line["roofline"]["issue_ceiling"] = issue
         if extra:
             line["extra_configs"] = extra
         if extra_error:
