@@ -561,15 +561,21 @@ struct FirB {
     bool n0, delta;    // order 0 (out = err, :260-267) / order 31 (out = sx(prev + err), :268-282)
 };
 
-// All-reduce over the 8 lanes of a stream / inclusive suffix sum over them (lane jl gets the sum over lanes >= jl).
+// All-reduce over the L lanes of a stream / inclusive suffix sum over them (lane jl gets the sum over lanes >= jl) / the DPP
+// control that moves a value one lane of the stream up.  L = 8: the lanes of a stream are every other lane of a row of 16
+// (two streams per row); L = 16: a row is a stream (orders above 16: two FIR waves of four streams share the 8 streams).
+template <int L>
 __device__ __forceinline__ int firb_allreduce(int p) {
+    if (L == 16) p = wadd(p, dpp0<DPP_QUAD_1032>(p));
     p = wadd(p, dpp0<DPP_QUAD_2301>(p));
     p = wadd(p, __builtin_amdgcn_update_dpp(0, p, DPP_ROW_ROR4, 0xF, 0xF, false));
     p = wadd(p, __builtin_amdgcn_update_dpp(0, p, DPP_ROW_ROR8, 0xF, 0xF, false));
     asm("" : "+v"(p));   // keep the last stage a one-instruction v_add_u32_dpp (merged into a v_add3 it needs a v_mov_dpp first)
     return p;
 }
+template <int L>
 __device__ __forceinline__ uint32_t firb_suffix(uint32_t v) {
+    if (L == 16) v += (uint32_t)dpp0<DPP_ROW_SHL1>((int)v);
     v += (uint32_t)dpp0<DPP_ROW_SHL_2>((int)v);
     v += (uint32_t)dpp0<DPP_ROW_SHL_4>((int)v);
     v += (uint32_t)dpp0<DPP_ROW_SHL_8>((int)v);
@@ -579,7 +585,7 @@ __device__ __forceinline__ uint32_t firb_suffix(uint32_t v) {
 // Steady state (every stream of the wave switched on and past its warm-up, i > N, no first sample left in a window).
 // WIDE: some stream of the wave has rss > 23 (the 24-bit multiply-add would drop bits of hist - base; the clamp keeps the
 // suffix sums from wrapping).  SPECIAL: some stream is of order 0 or 31.  PH: step number mod T (register rotation).
-template <int T, bool WIDE, bool SPECIAL, int PH, typename E>
+template <int T, bool WIDE, bool SPECIAL, int PH, int L, typename E>
 __device__ __forceinline__ void firb_step(FirB<T>& f, const E e) {
     constexpr bool SHORT = sizeof(E) == sizeof(XQ8);
     XQ x;
@@ -612,18 +618,18 @@ __device__ __forceinline__ void firb_step(FirB<T>& f, const E e) {
         if (WIDE && T == 1) cc[r] = min(cc[r], 1u << 26);                     // keeps the scan from wrapping; decisions unchanged: |err| < 2^26
         sd[r] = med3_i32(d[r], f.tlo[r], f.thi[r]);                           // sign(hist - base) on tap lanes
     }
-    const int sum = firb_allreduce(p);
+    const int sum = firb_allreduce<L>(p);
     const int xu = wadd(wadd(sum >> f.q, f.base), x.err);                     // :306-308 (biased through the base)
     int out = (int)__builtin_amdgcn_ubfe((uint32_t)xu, 0u, (uint32_t)f.rss); // :309-310
     if (SPECIAL) out = f.n0 ? wadd(x.err, f.bias) : out;                      // order 0 copies (:260-267)
     bool visit[T];
     if (T == 1) {
-        visit[0] = x.mag + cc[0] > firb_suffix(cc[0]);
+        visit[0] = x.mag + cc[0] > firb_suffix<L>(cc[0]);
     } else if (!WIDE) {
         uint32_t tot = cc[0];
 #pragma unroll
         for (int r = 1; r < T; r++) tot += cc[r];
-        uint32_t run = firb_suffix(tot) - tot;                                // the lanes above
+        uint32_t run = firb_suffix<L>(tot) - tot;                             // the lanes above
 #pragma unroll
         for (int r = T - 1; r >= 0; r--) { visit[r] = x.mag > run; run += cc[r]; }
     } else {
@@ -632,8 +638,8 @@ __device__ __forceinline__ void firb_step(FirB<T>& f, const E e) {
         uint32_t tot = cc[0];
 #pragma unroll
         for (int r = 1; r < T; r++) tot = __builtin_elementwise_add_sat(tot, cc[r]);
-        tot = min(tot, 1u << 28);
-        uint32_t run = firb_suffix(tot) - tot;                                // <= 7 x 2^28
+        tot = min(tot, L == 16 ? 1u << 27 : 1u << 28);                        // (above any |err|; L of them do not wrap)
+        uint32_t run = firb_suffix<L>(tot) - tot;
 #pragma unroll
         for (int r = T - 1; r >= 0; r--) { visit[r] = x.mag > run; run = __builtin_elementwise_add_sat(run, cc[r]); }
     }
@@ -647,14 +653,14 @@ __device__ __forceinline__ void firb_step(FirB<T>& f, const E e) {
         if (SHORT) f.c[r] = xad_u32(sdv, smask, wsub(f.c[r], smask));
         else f.c[r] = mad_i24(sdv, x.sgn, f.c[r]);
     }
-    f.h[PL] = __builtin_amdgcn_update_dpp(out, f.h[PL], DPP_ROW_SHR2, 0xF, 0xF, false);
+    f.h[PL] = __builtin_amdgcn_update_dpp(out, f.h[PL], L == 16 ? DPP_ROW_SHR1 : DPP_ROW_SHR2, 0xF, 0xF, false);
     f.base = (SPECIAL && f.delta) ? out : nb;
 }
 
 // Every case, on signed differences: the first sample (:260), the warm-up samples (:284-293), orders 0 and 31, streams that
 // are switched off or have ended (`active` false), the chunk in which a stream ends.  Register rotation phase 0 on entry
 // and exit.  `err` is the residual, `sgn` its sign mask (err >> 31).
-template <int T>
+template <int T, int L>
 __device__ __forceinline__ void firb_step_masked(FirB<T>& f, int err, int i, bool active) {
     int src = f.h[0];
 #pragma unroll
@@ -667,7 +673,7 @@ __device__ __forceinline__ void firb_step_masked(FirB<T>& f, int err, int i, boo
         d[r] = wsub(f.h[r], f.base);
         p = wadd(p, wmul(d[r], f.c[r]));
     }
-    const int sum = firb_allreduce(p);
+    const int sum = firb_allreduce<L>(p);
     const int xu = wadd(wadd(sum >> f.q, f.base), err);
     const bool general = f.N >= 1 && f.N <= 30 && i > f.N;
     int out;
@@ -685,7 +691,7 @@ __device__ __forceinline__ void firb_step_masked(FirB<T>& f, int err, int i, boo
         cc[r] = min(((uint32_t)(a + (s & f.qmask)) >> f.q) * f.w[r], 1u << 26);
         tot += cc[r];
     }
-    uint32_t run = firb_suffix(tot) - tot;
+    uint32_t run = firb_suffix<L>(tot) - tot;
     const bool live = general && active;
 #pragma unroll
     for (int r = T - 1; r >= 0; r--) {
@@ -693,7 +699,7 @@ __device__ __forceinline__ void firb_step_masked(FirB<T>& f, int err, int i, boo
         f.c[r] += (live && E > run) ? (sdr ^ s) - s : 0;
         run += cc[r];
     }
-    const int h0 = __builtin_amdgcn_update_dpp(out, f.h[T - 1], DPP_ROW_SHR2, 0xF, 0xF, false);
+    const int h0 = __builtin_amdgcn_update_dpp(out, f.h[T - 1], L == 16 ? DPP_ROW_SHR1 : DPP_ROW_SHR2, 0xF, 0xF, false);
     if (active) {
 #pragma unroll
         for (int r = T - 1; r >= 1; r--) f.h[r] = f.h[r - 1];

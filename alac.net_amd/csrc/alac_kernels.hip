@@ -224,6 +224,9 @@ __device__ __forceinline__ int mirror_i(int v, int src) { return __shfl(v, src, 
 #ifndef ALAC_AB_CHUNK
 #define ALAC_AB_CHUNK 32
 #endif
+#ifndef ALAC_L16_MAX_GROUPS
+#define ALAC_L16_MAX_GROUPS 256     // groups of 8 packets in the launch (= one workgroup per CU) up to which orders above 16 take two FIR waves
+#endif
 constexpr int AB_CHUNK = ALAC_AB_CHUNK;   // samples per barrier (16 were measured too: the critical wave pays its per-chunk overhead twice as often)
 // NS = streams (packets) per workgroup: 8 (one entropy wave of 8 lanes per stream, one FIR wave, one output wave) or 16 (the
 // "dense" arrangement for big batches: ONE entropy wave serves 16 streams with 4 lanes each -- its instructions are shared
@@ -484,29 +487,31 @@ __device__ __forceinline__ void ab_entropy_wave(const alac_decode_params& p, uin
 
 // The 32 steady-state steps of a chunk as one straight-line block (a lone wave pays for every block boundary); I = step
 // number inside the chunk, I % T = the register rotation phase (0 again at every multiple of 8).
-template <int T, bool WIDE, bool SPECIAL, int NS, int I>
+template <int T, bool WIDE, bool SPECIAL, int NS, int L, int I>
 __device__ __forceinline__ void ab_fir_block(FirB<T>& f, const typename XqSel<NS>::type* q, typename XqSel<NS>::type x, int* oq,
                                              const int (&oidx)[T]) {
     if constexpr (I < AB_CHUNK) {
         // the next step's residual is fetched one step ahead (an LDS read takes a good hundred cycles to come back)
         const typename XqSel<NS>::type xn = q[(I + 1 < AB_CHUNK ? I + 1 : I) * (NS + 1)];
-        firb_step<T, WIDE, SPECIAL, I % T>(f, x);
+        firb_step<T, WIDE, SPECIAL, I % T, L>(f, x);
         if constexpr ((I & 7) == 7) {
 #pragma unroll
             for (int r = 0; r < T; r++) oq[(I >> 3) * (NS * 8 + 64) + oidx[r]] = f.h[r];
         }
-        ab_fir_block<T, WIDE, SPECIAL, NS, I + 1>(f, q, xn, oq, oidx);
+        ab_fir_block<T, WIDE, SPECIAL, NS, L, I + 1>(f, q, xn, oq, oidx);
     }
 }
 
-// FIR wave (alac_device.h: the blocked layout): 8 lanes per stream, T taps per lane; the two parities of a row of 16 lanes
-// hold the SAME channel of two different packets, so one wave serves the 8 streams of a pass.
-// w: which block of 8 streams of the workgroup this wave serves (always 0 when NS == 8).
-template <int T, bool WIDE, bool SPECIAL, int NS>
+// FIR wave (alac_device.h: the blocked layout), T taps per lane.  L = 8 lanes per stream: the two parities of a row of 16 lanes
+// hold the SAME channel of two different packets, so one wave serves the 8 streams of a pass; w: which block of 8 streams of
+// the workgroup this wave serves (always 0 when NS == 8).  L = 16 (orders above 16): a row per stream, TWO waves share the 8
+// streams of the workgroup (w = 0 / 1: streams 0..3 / 4..7): half the taps per lane, so a step of either wave is a little more
+// than half as long -- and the FIR step's serial chain is what such a workgroup waits for.
+template <int T, bool WIDE, bool SPECIAL, int NS, int L = 8>
 __device__ __forceinline__ void ab_fir_wave(const alac_decode_params& p, uint32_t pkt0, int w, int lane, AbSharedT<NS>& sh, int ph, int nchunks) {
     constexpr int QS = NS + 1;
-    const int row = lane >> 4, l = lane & 15, par = l & 1, jl = l >> 1;
-    const int g = 8 * w + 2 * row + par;
+    const int row = lane >> 4, l = lane & 15, par = L == 16 ? 0 : l & 1, jl = L == 16 ? l : l >> 1;
+    const int g = L == 16 ? 4 * w + row : 8 * w + 2 * row + par;
     const uint32_t pkt = pkt0 + (uint32_t)g;
     const bool valid = pkt < p.n_packets;
     alacgpu_cfg_dev cfg;
@@ -541,10 +546,10 @@ __device__ __forceinline__ void ab_fir_wave(const alac_decode_params& p, uint32_
         f.thi[r] = tap ? 1 : 0;
         f.w[r] = tap ? (uint32_t)(N - t) : 0u;
         // tap t < 8 -> the lane 2 t + par of the row (what the output wave's lane wants); the others: the spare ints behind
-        oidx[r] = t < 8 ? 64 * w + (lane & 48) + 2 * t + par : NS * 8 + lane;
+        oidx[r] = t < 8 ? 16 * (g >> 1) + 2 * t + (g & 1) : NS * 8 + lane;
     }
     const int tl = gen ? N - 1 : 0;
-    f.bpaddr = ((lane & 48) + 2 * (tl / T) + par) * 4;
+    f.bpaddr = ((lane & 48) + (L == 16 ? tl / T : 2 * (tl / T) + par)) * 4;
     f.bsel = tl % T;
     const int nmax = __builtin_amdgcn_readfirstlane(wave_max(n_row));
     const int nmin_on = __builtin_amdgcn_readfirstlane(-wave_max(stream_on ? -n_row : (int)0x80000001));
@@ -564,7 +569,7 @@ __device__ __forceinline__ void ab_fir_wave(const alac_decode_params& p, uint32_
         if (__builtin_expect(c >= c_fast, 0))
             fast = fast && i0 + AB_CHUNK <= nmax && __builtin_amdgcn_ballot_w64(i0 < n_row && i0 + AB_CHUNK > n_row) == 0;
         if (__builtin_expect(fast, 1)) {
-            ab_fir_block<T, WIDE, SPECIAL, NS, 0>(f, q, q[0], oq, oidx);
+            ab_fir_block<T, WIDE, SPECIAL, NS, L, 0>(f, q, q[0], oq, oidx);
             continue;
         }
 #pragma unroll 1
@@ -574,7 +579,7 @@ __device__ __forceinline__ void ab_fir_wave(const alac_decode_params& p, uint32_
 #pragma unroll 1
                 for (int ii = 0; ii < 8; ii++) {
                     const int i = ih + ii;
-                    firb_step_masked<T>(f, q[(8 * half + ii) * QS].err, i, i < n_row);
+                    firb_step_masked<T, L>(f, q[(8 * half + ii) * QS].err, i, i < n_row);
                 }
             }
 #pragma unroll
@@ -910,7 +915,12 @@ __device__ __forceinline__ void ab_kernel_body(const alac_decode_params& p, AbSh
         const uint32_t used = (1u << sh.ring_on[0]) | (1u << sh.ring_on[1]) | (1u << sh.ring_on[2]) | (1u << sh.ring_on[3]);
         if (used == 15u) role = (int)((my_simd - sh.ring_next[NS - 1]) & 3u);       // (else: not one wave per SIMD -- wave order)
     }
-    if (NS == 8 && role == 3) return;     // the fourth wave was only there to claim the fourth SIMD
+    // Orders above 16: small batches (one workgroup per CU at most: every heavy wave has a SIMD to itself and the launch is as
+    // long as the FIR step's serial chain) split the 8 streams over TWO FIR waves with 16 lanes per stream and two taps per lane
+    // (a step of 41 issue slots instead of 65); bigger batches, where the SIMDs are shared, take the ONE wave with 8 lanes per
+    // stream and four taps per lane (65 slots per 8 streams instead of 2 x 41).  Measured: profiles/experiments/r3_fir_16_lanes.txt
+    const bool two_fir = TSEL == 4 && gridDim.x <= (unsigned)ALAC_L16_MAX_GROUPS;
+    if (NS == 8 && !two_fir && role == 3) return;     // the fourth wave was only there to claim the fourth SIMD
     wg_sync();
     if (role == 0) {
         __builtin_amdgcn_s_setprio(ALAC_ENTROPY_PRIO);
@@ -921,7 +931,13 @@ __device__ __forceinline__ void ab_kernel_body(const alac_decode_params& p, AbSh
         __builtin_amdgcn_s_setprio(1);   // above the output waves, below the entropy waves (8192 packets: 1.074 -> 1.048 ms, cfg3 3.33 -> 3.25)
         const int w = role - 2;
         const bool wr = w ? wrss1 : wrss0;
-        if constexpr (TSEL == 4) ab_fir_role<4, true, NS>(p, pkt0, w, lane, sh, nch0, nch1, true);
+        if constexpr (TSEL == 4) {
+            if (two_fir) {
+                for (int ph = 0; ph < (nch1 > 0 ? 2 : 1); ph++) ab_fir_wave<2, true, true, NS, 16>(p, pkt0, w, lane, sh, ph, ph ? nch1 : nch0);
+            } else {
+                ab_fir_role<4, true, NS>(p, pkt0, w, lane, sh, nch0, nch1, true);
+            }
+        }
         else if constexpr (TSEL == 2) ab_fir_role<2, false, NS>(p, pkt0, w, lane, sh, nch0, nch1, wr);
         else if constexpr (TSEL == 1) ab_fir_role<1, false, NS>(p, pkt0, w, lane, sh, nch0, nch1, wr);
         else if (__builtin_expect(!(w ? two1 : two0), 1)) ab_fir_role<1, false, NS>(p, pkt0, w, lane, sh, nch0, nch1, wr);
