@@ -38,6 +38,12 @@ struct alac_decode_params {
     int32_t* out_samples;       // may be null
     int32_t* status;
     uint32_t out_format;        // 0: one int32 per sample; 1: packed little-endian PCM bytes (FormatSamples fused)
+    // Where channel A of a two-channel packet waits between the two passes: null = in the packet's own output slot (ints
+    // [n, 2n)); else packet p's place is park + p * park_stride (>= n ints each).  The host-buffer entry point uses a place
+    // of its own when pcm_out is page-locked HOST memory the kernels store into directly: the parked samples are read back,
+    // and a read across the link costs what the whole decode costs.
+    int32_t* park;
+    uint32_t park_stride;
 #ifdef ALAC_DIAG
     unsigned long long* dbg;    // diagnostic build (make diag) only: 8 stamps per workgroup, see alac_diag.h
 #endif

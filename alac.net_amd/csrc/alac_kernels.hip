@@ -693,7 +693,7 @@ struct AbOutBlock {
         bias = 1 << (m.rss - 1);
         two_pass = n_out > 0 && m.stereo && !m.esc;   // A is parked in pass 0 and finished in pass 1
         pcm_slot = p.pcm_out + (int64_t)pkt * p.slot_ints;
-        park = pcm_slot + m.n;
+        park = p.park ? p.park + (int64_t)pkt * p.park_stride : pcm_slot + m.n;
 #pragma unroll
         for (int h = 0; h < AB_CHUNK / 8; h++) a_next[h] = 0;
         cs = 8 * w + (lane & 7);

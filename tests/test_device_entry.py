@@ -166,6 +166,45 @@ def test_pinned_buffers_and_chunked_host_path(pkg, oracle, synth):
         assert np.array_equal(st, ref[3][perm]) and _same_pcm(b, pcm, ref, perm)
 
 
+def test_page_locked_output_is_written_by_the_kernels_directly(pkg, oracle, synth, monkeypatch):
+    # alacgpu_decode_batch with page-locked pcm_out: no download, the kernels store into the caller's memory and channel A is
+    # parked in device memory (alac_decode_params::park); ALACGPU_ZERO_COPY=0 takes the copying path.  Same results, both
+    # output formats, a slot interior offset (a view into a bigger page-locked buffer), the single-packet entry point.
+    b = synth.make_config_batch(5, n_packets=1300)
+    ref = _oracle(oracle, b)
+    slot = int(b["slot_ints"])
+    with pkg.PinnedBuffer((1300 + 3, slot), np.int32) as pp:
+        for zc in ("1", "0"):
+            monkeypatch.setenv("ALACGPU_ZERO_COPY", zc)
+            with pkg.AlacGpuContext(b["stream_cfgs"]) as ctx:
+                pp.array[:] = 0x5A5A5A5A
+                view = pp.array[2:1302]                       # starts inside the page-locked allocation
+                pcm, ob, os_, st = ctx.decode_batch(b["blob"], b["offsets"], b["sizes"], b["cfg_idx"], slot, out=view)
+                assert np.array_equal(st, ref[3]) and np.array_equal(ob, ref[1]) and np.array_equal(os_, ref[2])
+                assert _same_pcm(b, pcm, ref)
+                assert (pp.array[:2] == 0x5A5A5A5A).all() and (pp.array[1302:] == 0x5A5A5A5A).all()   # nothing outside the view
+                if zc == "1":
+                    # nothing but the packet's own samples was written (the parked channel went to device memory)
+                    p = int(np.nonzero((ref[3] == 0) & (ref[2] > 0) & (ref[2] < 4096))[0][0])
+                    cnt = int(ref[2][p]) * int(b["stream_cfgs"][int(b["cfg_idx"][p])][5])
+                    assert (view[p, cnt:] == 0x5A5A5A5A).all()
+                ctx.set_output_format(1)
+                pcm2, ob2, _, st2 = ctx.decode_batch(b["blob"], b["offsets"], b["sizes"], b["cfg_idx"], slot, out=view)
+                assert np.array_equal(st2, ref[3]) and np.array_equal(ob2, ref[1])
+                for p in range(0, 1300, 37):
+                    if ref[3][p] != 0:
+                        continue
+                    cfg = b["stream_cfgs"][int(b["cfg_idx"][p])]
+                    bps, cnt = int(cfg[1]) // 8, int(ref[2][p]) * int(cfg[5])
+                    v = ref[0][p, :cnt].astype(np.int64)
+                    exp = np.stack([(v >> (8 * k)) & 255 for k in range(bps)], axis=1).astype(np.uint8).reshape(-1)
+                    assert np.array_equal(pcm2[p].view(np.uint8)[: cnt * bps], exp), p
+                ctx.set_output_format(0)
+                o0, s0 = int(b["offsets"][0]), int(b["sizes"][0])
+                refints, rob, rst = ctx.decode_frame(int(b["cfg_idx"][0]), b["blob"][o0:o0 + s0])
+                assert rst == ref[3][0] and rob == ref[1][0]
+
+
 def test_one_batch_over_several_contexts_from_one_process(pkg, oracle, synth):
     # alacgpu_decode_batch_sharded: how a single-process host uses every GPU of a node (one context per device, one native
     # thread each).  One GPU here, so three contexts on the same device; uneven ranges and a batch smaller than the
