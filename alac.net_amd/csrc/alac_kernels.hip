@@ -110,6 +110,18 @@ __device__ __forceinline__ void spec_unpark(Rice& rs, const Rice& snap, bool par
     }
 }
 
+// Queue stores of a unit: with a row per stream (QSTRIDE 1) four values go out in ONE 16-byte store -- every LDS instruction
+// is an issue slot of the wave that has none to spare.
+template <int QSTRIDE>
+__device__ __forceinline__ void spec_store(int* q, int ii, int (&acc)[4], int r) {
+    if (QSTRIDE == 1) {
+        acc[ii & 3] = r;
+        if ((ii & 3) == 3) *reinterpret_cast<int4*>(q + (ii & ~3)) = make_int4(acc[0], acc[1], acc[2], acc[3]);
+    } else {
+        q[ii * QSTRIDE] = r;
+    }
+}
+
 template <bool WANT_R, int QSTRIDE, bool RAW = false>
 __device__ __forceinline__ bool spec_unit(Rice& rs, TierState& ts, const RiceCfg& c, uint32_t ring, int* q, SpecStats& st) {
     const Rice snap = rs;
@@ -120,12 +132,13 @@ __device__ __forceinline__ bool spec_unit(Rice& rs, TierState& ts, const RiceCfg
     const bool special = __builtin_amdgcn_ballot_w64(rs.nforce == 0u && !parked) != 0;
     uint32_t xmax = 0, vmax = 0;
     int hmin = 0x7FFFFFFF;
+    int acc[4] = {0, 0, 0, 0};
     if (ts.full_left == 0) {
         if (!special) {
 #pragma unroll
             for (int ii = 0; ii < SPEC_UNIT; ii++) {
                 const int r = rice_spec_step<WANT_R, RAW>(rs, c, ring, xmax, hmin, vmax);
-                if (WANT_R) q[ii * QSTRIDE] = r;
+                if (WANT_R) spec_store<QSTRIDE>(q, ii, acc, r);
             }
             spec_unpark<WANT_R, QSTRIDE>(rs, snap, parked, xmax, hmin, q);
             vmax = parked ? 0u : vmax;
@@ -133,7 +146,7 @@ __device__ __forceinline__ bool spec_unit(Rice& rs, TierState& ts, const RiceCfg
 #pragma unroll
             for (int ii = 0; ii < SPEC_UNIT; ii++) {
                 const int r = rice_spec_step_z<WANT_R, RAW>(rs, c, ring, xmax, hmin);
-                if (WANT_R) q[ii * QSTRIDE] = r;
+                if (WANT_R) spec_store<QSTRIDE>(q, ii, acc, r);
             }
             rs.nforce = (rs.zrun > 0 || rs.signmod != 0) ? 0u : 0xFFFFFFFFu;
         }
@@ -153,7 +166,7 @@ __device__ __forceinline__ bool spec_unit(Rice& rs, TierState& ts, const RiceCfg
 #pragma unroll
         for (int ii = 0; ii < SPEC_UNIT; ii++) {
             const int r = rice_spec_step_esc<WANT_R, RAW>(rs, c, ring, xmax, hmin);
-            if (WANT_R) q[ii * QSTRIDE] = r;
+            if (WANT_R) spec_store<QSTRIDE>(q, ii, acc, r);
         }
         spec_unpark<WANT_R, QSTRIDE>(rs, snap, parked, xmax, hmin, q);
         const bool sawesc = __builtin_amdgcn_ballot_w64(xmax > 8u) != 0;
@@ -165,7 +178,7 @@ __device__ __forceinline__ bool spec_unit(Rice& rs, TierState& ts, const RiceCfg
 #pragma unroll
         for (int ii = 0; ii < SPEC_UNIT; ii++) {
             const int r = rice_spec_step_esc_wide<WANT_R, RAW>(rs, w3, c, ring, xmax, hmin);
-            if (WANT_R) q[ii * QSTRIDE] = r;
+            if (WANT_R) spec_store<QSTRIDE>(q, ii, acc, r);
         }
         spec_unpark<WANT_R, QSTRIDE>(rs, snap, parked, xmax, hmin, q);
         const bool sawesc = __builtin_amdgcn_ballot_w64(xmax > 8u) != 0;
@@ -177,7 +190,7 @@ __device__ __forceinline__ bool spec_unit(Rice& rs, TierState& ts, const RiceCfg
 #pragma unroll
         for (int ii = 0; ii < SPEC_UNIT; ii++) {
             const int r = rice_spec_step_full<WANT_R, RAW>(rs, w3, c, ring, xmax, hmin);
-            if (WANT_R) q[ii * QSTRIDE] = r;
+            if (WANT_R) spec_store<QSTRIDE>(q, ii, acc, r);
         }
         rs.nforce = (rs.zrun > 0 || rs.signmod != 0) ? 0u : 0xFFFFFFFFu;
         const bool sawesc = __builtin_amdgcn_ballot_w64(xmax > 8u) != 0;
@@ -224,6 +237,15 @@ __device__ __forceinline__ int mirror_i(int v, int src) { return __shfl(v, src, 
 #ifndef ALAC_AB_CHUNK
 #define ALAC_AB_CHUNK 32
 #endif
+// Layout of the queue of code values (entropy wave -> output wave).  1: a row per stream, the 16 values of a speculative unit
+// side by side, stored four at a time (12 LDS instructions fewer per unit for the wave that has no issue slot to spare): the
+// latency-bound small-batch build, -3 % (cfg2 / cfg4 at 4096 packets).  0: a row per sample, one store per value: what the
+// other builds measured best with (the conversion's reads are conflict-free; cfg4 at 8192 packets +2 % with rows per stream,
+// cfg2 at 32768 +1 %).  profiles/experiments/r3_queue_rows.txt
+#ifndef ALAC_QROWS
+#define ALAC_QROWS 0
+#endif
+constexpr bool QROWS = ALAC_QROWS != 0;
 #ifndef ALAC_L16_MAX_GROUPS
 #define ALAC_L16_MAX_GROUPS 256     // groups of 8 packets in the launch (= one workgroup per CU) up to which orders above 16 take two FIR waves
 #endif
@@ -237,12 +259,14 @@ template <int NS>
 struct AbSharedT {
     typedef typename XqSel<NS>::type Xq;
     uint32_t rings[NS][RING_BYTES / 4];
-    int resq[2][AB_CHUNK][NS];           // entropy wave -> output wave: the unsigned Rice code values dv
+    // entropy wave -> output wave: the unsigned Rice code values dv.  QROWS: [stream][sample], rows 16-byte aligned and, with
+    // 4 ints of padding, spread over the banks; else [sample][stream]
+    int resq[2][QROWS ? NS : AB_CHUNK][QROWS ? AB_CHUNK + 4 : NS];
     Xq xq[2][AB_CHUNK][NS + 1];          // output wave -> FIR waves; column NS is never written and stays zero: what a
                                          // switched-off or finished stream is fed
     int outq[2][AB_CHUNK / 8][NS * 8 + 64];   // FIR wave w -> output wave (lanes 64 w ..), 8 outputs per stream per 8 samples; the 64
                                               // ints behind them: where FIR lanes that hold no tap below 8 write (no branch around a store)
-    int dummy[AB_CHUNK * NS + 64];       // where the entropy wave's lanes without a stream of their own write
+    int dummy[QROWS ? AB_CHUNK + 4 + 64 + 4 : AB_CHUNK * NS + 64];   // where the entropy wave's lanes without a stream of their own write
     uint32_t ring_next[NS];    // entropy wave -> output wave: Rice::next of the stream at the last barrier
     uint32_t ring_filled[NS];  // entropy wave -> output wave at the start of a pass: bytes staged by rice_init
     uint32_t ring_on[NS];      // stream switched on in this pass
@@ -358,20 +382,21 @@ __device__ __forceinline__ uint32_t ab_entropy_pass(const alac_decode_params& p,
         // The chunks that lie wholly inside every stream (all but the last one or two of a stretch) in a loop of their own: nothing
         // to decide per chunk (this wave pays for every block boundary: see the FIR waves).
         {
-            int* const qa = (sub == 0 && kreal) ? &sh.resq[0][0][g] : &sh.dummy[lane];
-            const int qodd = (sub == 0 && kreal) ? AB_CHUNK * S : 0;
+            int* const qa = (sub == 0 && kreal) ? (QROWS ? &sh.resq[0][g][0] : &sh.resq[0][0][g]) : &sh.dummy[QROWS ? 4 * (lane & 15) : lane];
+            const int qodd = (sub == 0 && kreal) ? AB_CHUNK * S + (QROWS ? 4 * S : 0) : 0;
+            constexpr int QS1 = QROWS ? 1 : S;        // distance of two samples of a stream in the queue
             const int cf_end = min(c_stop, knmin / AB_CHUNK);
             for (; c < cf_end; c++) {
                 const int i0 = c * AB_CHUNK;
                 int* q = qa + (c & 1) * qodd;
 #pragma unroll
                 for (int u = 0; u < AB_CHUNK; u += SPEC_UNIT) {
-                    const bool redo = !spec_unit<true, S, true>(rs, ts, kc, kring, q + u * S, st);
+                    const bool redo = !spec_unit<true, QS1, true>(rs, ts, kc, kring, q + u * QS1, st);
                     if (__builtin_expect(redo, 0)) {
                         SPEC_COUNT(redo);
                         for (int ii = 0; ii < SPEC_UNIT; ii++) {
                             const int r = rice_step(rs, kc, kn - 1 - (i0 + u + ii), i0 + u + ii, &flags, kring);
-                            q[(u + ii) * S] = ab_zigzag(r);
+                            q[(u + ii) * QS1] = ab_zigzag(r);
                         }
                     }
                 }
@@ -382,7 +407,8 @@ __device__ __forceinline__ uint32_t ab_entropy_pass(const alac_decode_params& p,
         }
         for (; c < c_stop; c++) {
             const int i0 = c * AB_CHUNK;
-            int* q = (sub == 0 && kreal) ? &sh.resq[c & 1][0][g] : &sh.dummy[lane];
+            constexpr int QS1 = QROWS ? 1 : S;
+            int* q = (sub == 0 && kreal) ? (QROWS ? &sh.resq[c & 1][g][0] : &sh.resq[c & 1][0][g]) : &sh.dummy[QROWS ? 4 * (lane & 15) : lane];
             if (i0 < nmax) {
                 // (a stream may END with the chunk: the reference reads no run symbol behind a stream's last sample, whatever the
                 // history -- AlacFile.cs:231 -- while the speculative step reports one; such a unit is then decoded by rice_step,
@@ -391,17 +417,17 @@ __device__ __forceinline__ uint32_t ab_entropy_pass(const alac_decode_params& p,
                 if (fast_chunk) {
 #pragma unroll
                     for (int u = 0; u < AB_CHUNK; u += SPEC_UNIT) {
-                        const bool redo = !spec_unit<true, S, true>(rs, ts, kc, kring, q + u * S, st);
+                        const bool redo = !spec_unit<true, QS1, true>(rs, ts, kc, kring, q + u * QS1, st);
                         if (redo) {
                             SPEC_COUNT(redo);
                             for (int ii = 0; ii < SPEC_UNIT; ii++) {
                                 const int r = rice_step(rs, kc, kn - 1 - (i0 + u + ii), i0 + u + ii, &flags, kring);
-                                q[(u + ii) * S] = ab_zigzag(r);
+                                q[(u + ii) * QS1] = ab_zigzag(r);
                             }
                         }
                     }
                 } else {      // some stream ends in this chunk (or one sample after it): shadows step with their source
-                    const int qstride = (sub == 0 && kreal) ? S : 0;
+                    const int qstride = (sub == 0 && kreal) ? QS1 : 0;
                     for (int ii = 0; ii < AB_CHUNK; ii++) {
                         const int i = i0 + ii;
                         int r = 0;
@@ -665,7 +691,7 @@ struct AbRefill {
 // (pass0_step) and of pass 1 (pass1_step).  One output wave serves one block (8-packet workgroups) or both blocks of a
 // 16-packet workgroup, one after the other, between the same two barriers.
 // Two lane -> stream mappings live here: the FIR wave's (lane 2 j + par of a row holds out[last - j] of stream 2 row + par),
-// for the queue of reconstructed samples, and a linear one (stream lane & 7, sample lane >> 3) for the conversion of the code
+// for the queue of reconstructed samples, and a linear one (stream lane & 7, sample lane >> 3; or the other way round, QROWS) for the conversion of the code
 // values and for the ring refill.
 template <int NS>
 struct AbOutBlock {
@@ -696,7 +722,7 @@ struct AbOutBlock {
         park = p.park ? p.park + (int64_t)pkt * p.park_stride : pcm_slot + m.n;
 #pragma unroll
         for (int h = 0; h < AB_CHUNK / 8; h++) a_next[h] = 0;
-        cs = 8 * w + (lane & 7);
+        cs = 8 * w + (QROWS ? lane >> 3 : lane & 7);
         const uint32_t cpkt = pkt0 + (uint32_t)cs;
         const bool cvalid = cpkt < p.n_packets;
         const Meta ca = parse_meta(p, cpkt, 0, cvalid, cfg);
@@ -706,13 +732,13 @@ struct AbOutBlock {
     }
     // after barrier b of a pass: chunk b's code values -> what the FIR step wants (four residuals per lane)
     __device__ __forceinline__ void convert(int b, int ph) {
-        const int (*src)[NS] = sh.resq[b & 1];
+        const auto& src = sh.resq[b & 1];
         typename XqSel<NS>::type (*dst)[NS + 1] = sh.xq[b & 1];
 #pragma unroll
         for (int k = 0; k < AB_CHUNK / 8; k++) {
-            const int i = (lane >> 3) + 8 * k;
+            const int i = QROWS ? (lane & 7) + 8 * k : (lane >> 3) + 8 * k;
             typename XqSel<NS>::type x;
-            xq_from_code(x, (uint32_t)src[i][cs], cq[ph]);
+            xq_from_code(x, (uint32_t)(QROWS ? src[cs][i] : src[i][cs]), cq[ph]);
             dst[i][cs] = x;
         }
     }

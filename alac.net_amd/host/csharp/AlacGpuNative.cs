@@ -56,6 +56,28 @@ namespace ALACdotNET.Decoder
         [DllImport(Lib)] public static extern IntPtr alacgpu_status_string(int status);
         [DllImport(Lib)] public static extern IntPtr alacgpu_strerror(int rc);
         [DllImport(Lib)] public static extern IntPtr alacgpu_last_error(IntPtr ctx);
+        [DllImport(Lib)] public static extern int alacgpu_ctx_device(IntPtr ctx);
+
+        // ---- multi-GPU, one process per GPU: the packet partition and the RCCL all-gather of decoded PCM (include/alacgpu.h) ----
+        public const int CommIdBytes = 128;
+        /// <summary>first[world + 1]: rank r owns packets first[r] .. first[r+1] (whole groups of 8, balanced by packet bytes).</summary>
+        [DllImport(Lib)] public static extern int alacgpu_shard_ranges([In] uint[] sizes, uint nPackets, uint world, [Out] uint[] first);
+        /// <summary>Rank 0: 128 bytes to hand to the other ranks (pipe, socket, file ...) before alacgpu_comm_create.</summary>
+        [DllImport(Lib)] public static extern int alacgpu_comm_get_unique_id([Out] byte[] id128);
+        /// <summary>Collective (ncclCommInitRank): every rank calls it with the same id.</summary>
+        [DllImport(Lib)] public static extern int alacgpu_comm_create(IntPtr ctx, [In] byte[] id128, int rank, int world, out IntPtr comm);
+        [DllImport(Lib)] public static extern void alacgpu_comm_destroy(IntPtr comm);
+        [DllImport(Lib)] public static extern int alacgpu_comm_rank(IntPtr comm);
+        [DllImport(Lib)] public static extern int alacgpu_comm_world(IntPtr comm);
+        [DllImport(Lib)] public static extern IntPtr alacgpu_comm_last_error(IntPtr comm);
+        /// <summary>dFullPcm (device memory, the whole batch's slots in global packet order) holds this rank's packets decoded
+        /// in place; on return -- asynchronous on hipStream -- every rank holds every packet (ncclAllGather, int32).</summary>
+        [DllImport(Lib)] public static extern int alacgpu_allgather_pcm(IntPtr comm, IntPtr dFullPcm, [In] uint[] first, uint slotInts, IntPtr hipStream);
+        /// <summary>Decode this rank's range in up to four pieces and gather piece k while piece k + 1 decodes; all device arrays are
+        /// indexed by GLOBAL packet number.</summary>
+        [DllImport(Lib)] public static extern int alacgpu_decode_allgather_device(IntPtr ctx, IntPtr comm, IntPtr dBlob, ulong blobBytes,
+            IntPtr dOffsets, IntPtr dSizes, IntPtr dCfgIdx, [In] uint[] first, IntPtr dFullPcm, uint slotInts,
+            IntPtr dOutBytes, IntPtr dOutSamples, IntPtr dStatus, uint nChunks, IntPtr hipStream);
 
         public static string Error(int rc) => Marshal.PtrToStringAnsi(alacgpu_strerror(rc));
     }
