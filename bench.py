@@ -271,9 +271,18 @@ def measure_allgather_native(pkg, torch, dist, np, w, world, rank, dev, cdev, re
     overlapped form with its own collective stream): what a native host (the C# AlacContext) gets.  Weak scaling: every
     rank's shard has n packets, global packet r*n + i = rank r's packet i.  Returns (alone ms, overlapped ms, ok)."""
     n, slot = w.n_packets, w.slot
-    uid = torch.zeros(128, dtype=torch.uint8, device=cdev)
-    if rank == 0:
-        uid.copy_(torch.from_numpy(pkg.AlacGpuComm.unique_id()).to(cdev))
+    # every rank first finds out, by itself, whether RCCL loads through the library (an id made here and thrown away), and the
+    # ranks agree on the answer BEFORE anything collective happens through the C ABI: a rank that failed alone would leave the
+    # others waiting in ncclCommInitRank
+    try:
+        my_id, ok_here = pkg.AlacGpuComm.unique_id(), 1
+    except Exception:   # noqa: BLE001
+        my_id, ok_here = np.zeros(128, dtype=np.uint8), 0
+    flag = torch.tensor([ok_here], dtype=torch.int32, device=cdev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        raise RuntimeError("RCCL not loadable through libalacgpu.so on some rank")
+    uid = torch.from_numpy(my_id).to(cdev)
     dist.broadcast(uid, src=0)
     first = np.arange(world + 1, dtype=np.uint32) * n
     with pkg.AlacGpuComm(w.ctx, uid.cpu().numpy(), rank, world) as comm:
@@ -325,13 +334,19 @@ def gather_figures(pkg, torch, dist, sharding, np, w, world, rank, dev, cdev, ba
     HBM (backend nccl), through torch.distributed otherwise (gloo rehearsals) -- or when the native path fails, which the
     line then says."""
     if backend == "nccl":
+        err = None
         try:
             a, o, ok = measure_allgather_native(pkg, torch, dist, np, w, world, rank, dev, cdev)
-            return a, o, ok, "alacgpu_comm (C ABI, RCCL)"
         except Exception as e:   # noqa: BLE001
-            note = f"alacgpu_comm failed ({type(e).__name__}: {e}); torch.distributed instead"[:300]
-            a, o, ok = measure_allgather(torch, dist, sharding, w, world, rank, dev, backend)
-            return a, o, ok, note
+            err = f"{type(e).__name__}: {e}"
+        # all ranks take the same road from here on
+        bad = torch.tensor([1 if err else 0], dtype=torch.int32, device=cdev)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if int(bad.item()) == 0:
+            return a, o, ok, "alacgpu_comm (C ABI, RCCL)"
+        note = f"alacgpu_comm failed ({err or 'on another rank'}); torch.distributed instead"[:300]
+        a, o, ok = measure_allgather(torch, dist, sharding, w, world, rank, dev, backend)
+        return a, o, ok, note
     a, o, ok = measure_allgather(torch, dist, sharding, w, world, rank, dev, backend)
     return a, o, ok, f"torch.distributed ({backend})"
 

@@ -44,7 +44,12 @@ def main():
         stereo, is24 = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
         orders = [np.arange(0, 32), np.arange(1, 9), np.array([8]), np.arange(9, 17), np.arange(17, 32)][int(rng.integers(0, 5))]
         count = int(rng.integers(1, 97))
+        big = rng.random() < 0.08     # more than 256 groups of 8: orders above 16 then take ONE FIR wave with four taps per lane
+        if big:
+            count = int(rng.integers(2049, 2300))
         d = recipes(rng, count, stereo, is24, orders)
+        if big:
+            d["n"] = np.minimum(d["n"], rng.integers(33, 700, count))
         if stereo and rng.random() < 0.3:
             d["stereo"] = rng.integers(0, 2, count)     # one-channel elements inside a two-channel stream: L = sample, R = 0
         sig = synth.default_signal(int(rng.integers(0, 1 << 31)))
@@ -59,7 +64,14 @@ def main():
         except RuntimeError:      # the synthetic encoder refuses a few random recipes (a value it cannot represent)
             skipped += 1
             continue
-        cfgs = [(4096, 24 if is24 else 16, 40, 10, 14, 2 if stereo else 1)]
+        kb = int(rng.choice([14, 14, 14, 9, 16, 17, 24, 33, 40, 255]))      # rice_kmodifier: any byte but 0 (AlacFile.cs:82)
+        d["rice_kmodifier"] = kb
+        try:
+            b = synth.make_batch(d, sig, want_pcm=True) if kb != 14 else b
+        except RuntimeError:
+            skipped += 1
+            continue
+        cfgs = [(4096, 24 if is24 else 16, 40, 10, kb, 2 if stereo else 1)]
         nc = 2 if stereo else 1
         b["slot_ints"] = int(d["n"].max()) * nc          # (one-channel elements in a two-channel stream still fill two channels)
         o = orc.decode_batch(orc.make_cfgs(cfgs), b["blob"], b["offsets"], b["sizes"], None, b["slot_ints"], n_threads=8)
