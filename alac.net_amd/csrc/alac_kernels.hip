@@ -615,12 +615,36 @@ __device__ __forceinline__ void ab_fir_wave(const alac_decode_params& p, uint32_
     wg_sync();  // final barrier of the pass
 }
 
-// 24-bit streams: merge the sample's shift bytes (AlacFile.cs:390-395) and sign-extend to 24 bits (:555-557).
-__device__ __forceinline__ int ab_finish24(const Meta& m, int val, int i, int chan) {
+// 24-bit streams: merge the sample's shift bytes (AlacFile.cs:390-395 / :476-482, :634-641) and sign-extend to 24 bits
+// (:555-557).  The shift bytes of sample i -- one field of 8 ub bits per channel, the channels side by side -- sit at bit
+// ubit + i * channels * 8 ub of the packet: at most 32 bits at any bit alignment, i.e. inside two big-endian dwords.  The
+// output wave fetches those two dwords ONE STEP AHEAD of the sample (ub_fetch; like the parked channel A), so that the
+// loads' latency -- a global load is a microsecond or two -- lies behind a chunk barrier instead of in front of every store
+// (cfg3: the output wave's exposed loads were a tenth of the 8-packet arrangement's time and a quarter of the dense one's).
+struct UbWin { uint32_t hi, lo; };
+__device__ __forceinline__ bool ab_has_ub(const Meta& m) { return m.ss == 24 && m.ub != 0 && !m.esc; }
+__device__ __forceinline__ UbWin ub_fetch(const Meta& m, int i, bool want) {
+    UbWin w;
+    w.hi = w.lo = 0;
+    if (want) {
+        const uint32_t bp = m.ubit + (uint32_t)(i * (m.stereo ? 2 : 1) * 8 * m.ub);
+        const int64_t d = (int64_t)(bp >> 5) * 4;
+        w.hi = load_be32(m.base, d, m.limit);
+        w.lo = load_be32(m.base, d + 4, m.limit);
+    }
+    return w;
+}
+// AHEAD false: the window is fetched here and now (the dense arrangement, see AbOutBlock::ub_step)
+template <bool AHEAD>
+__device__ __forceinline__ int ab_finish24(const Meta& m, UbWin w, int val, int i, int chan) {
     if (m.ss != 24) return val;
     if (m.ub != 0 && !m.esc) {
-        const uint32_t bp = m.ubit + (uint32_t)((i * (m.stereo ? 2 : 1) + chan) * 8 * m.ub);
-        val = (int)(((uint32_t)val << (8 * m.ub)) | peek_bits(m.base, m.limit, bp, 8 * m.ub));
+        if (!AHEAD) w = ub_fetch(m, i, true);
+        const uint32_t bp = m.ubit + (uint32_t)(i * (m.stereo ? 2 : 1) * 8 * m.ub);
+        const uint32_t off = (bp & 31u) + (uint32_t)(chan * 8 * m.ub);                    // <= 31 + 16
+        const uint64_t both = (((uint64_t)w.hi << 32) | w.lo) << off;
+        const uint32_t field = (uint32_t)(both >> 32) >> (32 - 8 * m.ub);
+        val = (int)(((uint32_t)val << (8 * m.ub)) | field);
     }
     return __builtin_amdgcn_sbfe(val, 0, 24);
 }
@@ -705,6 +729,7 @@ struct AbOutBlock {
     int32_t* park;
     AbRefill<NS> rf;
     int a_next[AB_CHUNK / 8];
+    UbWin ub_next[AB_CHUNK / 8];   // the shift-byte windows of the samples stored at the NEXT step
     int cs, cq[2];          // conversion: this lane's stream and the quantiser masks (1 << q) - 1 of its two channels
     __device__ AbOutBlock(const alac_decode_params& p_, uint32_t pkt0, int w_, int lane_, AbSharedT<NS>& sh_)
         : p(p_), sh(sh_), w(w_), lane(lane_), rf(p_, pkt0, w_, lane_, sh_) {
@@ -721,7 +746,7 @@ struct AbOutBlock {
         pcm_slot = p.pcm_out + (int64_t)pkt * p.slot_ints;
         park = p.park ? p.park + (int64_t)pkt * p.park_stride : pcm_slot + m.n;
 #pragma unroll
-        for (int h = 0; h < AB_CHUNK / 8; h++) a_next[h] = 0;
+        for (int h = 0; h < AB_CHUNK / 8; h++) { a_next[h] = 0; ub_next[h].hi = ub_next[h].lo = 0; }
         cs = 8 * w + (QROWS ? lane >> 3 : lane & 7);
         const uint32_t cpkt = pkt0 + (uint32_t)cs;
         const bool cvalid = cpkt < p.n_packets;
@@ -729,6 +754,23 @@ struct AbOutBlock {
         const Meta cb = parse_meta(p, cpkt, 1, cvalid, cfg);
         cq[0] = (1 << ca.q) - 1;
         cq[1] = (1 << cb.q) - 1;
+    }
+    // Shift-byte windows for the samples of chunk b-1, fetched one step AHEAD of their stores (they wait in 8 registers across
+    // the barrier).  8-packet arrangement only: the dense arrangement's kernel sits at its 128-register budget -- with these
+    // 16 more (its output wave serves two blocks) the compiler spilled, and not only in the output wave: cfg2 at 32768 packets
+    // 2.56 -> 3.24 ms -- so there the window is fetched where it is used, as in round 2.
+    static constexpr bool UB_AHEAD = NS == 8;
+    __device__ __forceinline__ void ub_step(int b, int nch, bool wanted, UbWin (&ub_cur)[AB_CHUNK / 8]) {
+        if (!UB_AHEAD) return;
+#pragma unroll
+        for (int h = 0; h < AB_CHUNK / 8; h++) ub_cur[h] = ub_next[h];
+        if (!wanted) return;
+#pragma unroll
+        for (int half = 0; half < AB_CHUNK / 8; half++) {
+            const int ih = (b - 1) * AB_CHUNK + 8 * half;
+            const int cnt = min(8, n_out - ih);
+            ub_next[half] = ub_fetch(m, ih + cnt - 1 - j, b >= 1 && b <= nch && j < cnt);
+        }
     }
     // after barrier b of a pass: chunk b's code values -> what the FIR step wants (four residuals per lane)
     __device__ __forceinline__ void convert(int b, int ph) {
@@ -744,7 +786,12 @@ struct AbOutBlock {
     }
     // after barrier b of pass 0: chunk b-2's outputs are in the queue
     __device__ __forceinline__ void pass0_step(int b, int nch0) {
-        if (b < nch0) { rf.issue(b == 0); convert(b, 0); }
+        if (b < nch0) rf.issue(b == 0);
+        UbWin ub_cur[AB_CHUNK / 8];
+#pragma unroll
+        for (int h = 0; h < AB_CHUNK / 8; h++) ub_cur[h].hi = ub_cur[h].lo = 0;
+        ub_step(b, nch0, !two_pass && ab_has_ub(m), ub_cur);
+        if (b < nch0) convert(b, 0);
         if (b >= 2) {
             const int c = b - 2;
 #pragma unroll
@@ -768,7 +815,7 @@ struct AbOutBlock {
                     if (two_pass) {
                         park[i] = mine;
                     } else {                                            // one channel: done
-                        store_sample(p, m, pcm_slot, (int64_t)i * m.nc, ab_finish24(m, mine, i, 0));
+                        store_sample(p, m, pcm_slot, (int64_t)i * m.nc, ab_finish24<UB_AHEAD>(m, ub_cur[half], mine, i, 0));
                         if (m.nc > 1) store_sample(p, m, pcm_slot, (int64_t)i * m.nc + 1, 0);
                     }
                 }
@@ -778,7 +825,12 @@ struct AbOutBlock {
     }
     // after barrier b of pass 1: B's chunk b-2 arrives, A comes back from its parking place (loaded one step ahead)
     __device__ __forceinline__ void pass1_step(int b, int nch1) {
-        if (b < nch1) { rf.issue(b == 0); convert(b, 1); }
+        if (b < nch1) rf.issue(b == 0);
+        UbWin ub_cur[AB_CHUNK / 8];
+#pragma unroll
+        for (int h = 0; h < AB_CHUNK / 8; h++) ub_cur[h].hi = ub_cur[h].lo = 0;
+        ub_step(b, nch1, two_pass && ab_has_ub(m), ub_cur);
+        if (b < nch1) convert(b, 1);
         int a_cur[AB_CHUNK / 8];
 #pragma unroll
         for (int h = 0; h < AB_CHUNK / 8; h++) a_cur[h] = a_next[h];
@@ -805,8 +857,8 @@ struct AbOutBlock {
                     left = a;
                     right = bb;
                 }
-                store_sample(p, m, pcm_slot, (int64_t)i * m.nc, ab_finish24(m, left, i, 0));
-                if (m.nc > 1) store_sample(p, m, pcm_slot, (int64_t)i * m.nc + 1, ab_finish24(m, right, i, 1));
+                store_sample(p, m, pcm_slot, (int64_t)i * m.nc, ab_finish24<UB_AHEAD>(m, ub_cur[half], left, i, 0));
+                if (m.nc > 1) store_sample(p, m, pcm_slot, (int64_t)i * m.nc + 1, ab_finish24<UB_AHEAD>(m, ub_cur[half], right, i, 1));
             }
         }
         if (b < nch1) rf.commit();

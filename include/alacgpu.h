@@ -167,8 +167,9 @@ int alacgpu_ctx_device(const alacgpu_ctx* ctx);
  * the same or on different streams (each owns its scratch until it has finished; a ninth call waits for the oldest).
  * The caller keeps every buffer alive and unchanged until the stream has passed the call.
  * Throughput: a launch of a few thousand packets is bound by the length of one packet's serial chain, not by the chip; a
- * caller with a stream of such batches keeps TWO in flight on two streams (0.78 -> 0.50 ms per batch of 4096 packets, DESIGN.md
- * section 4; streams that share one of the runtime's hardware queues do not overlap) -- or makes its batches bigger.
+ * caller with a stream of such batches keeps TWO in flight on two streams (0.70 -> about 0.5 ms per batch of 4096 packets,
+ * bench.py key two_in_flight; streams that share one of the runtime's hardware queues do not overlap) -- or makes its batches
+ * bigger.
  */
 int alacgpu_decode_batch_device(alacgpu_ctx* ctx, const void* d_blob, uint64_t blob_bytes, const void* d_offsets,
                                 const void* d_sizes, const void* d_cfg_idx, uint32_t n_packets, void* d_pcm_out,
@@ -203,9 +204,12 @@ float alacgpu_last_kernel_ms(alacgpu_ctx* ctx);
 enum { ALACGPU_OUT_INT32 = 0, ALACGPU_OUT_PACKED_LE = 1 };
 int alacgpu_set_output_format(alacgpu_ctx* ctx, int format);
 
-/* Page-locked host memory for batch buffers (blob, offsets, pcm_out ...): transfers from and to it are asynchronous.
- * Optional -- every entry point takes ordinary memory too (and on MI355X hosts runs at link speed, 55 GB/s, with it:
- * measured).  NULL on failure. */
+/* Page-locked host memory for batch buffers (blob, offsets, pcm_out ...).  Optional -- every entry point takes ordinary memory
+ * too -- but the faster choice: when pcm_out of alacgpu_decode_batch / alacgpu_decode_frame is page-locked (from here, from
+ * hipHostMalloc, or registered with hipHostRegister) the kernels store the PCM straight into it while the batch decodes and
+ * there is no download behind the decode (cfg2, 4096 packets: 3.55 / 2.39 ms int32 / packed against 3.70 / 2.50 ms from
+ * ordinary memory); what a slot holds beyond the packet's own output is then left untouched.
+ * ALACGPU_ZERO_COPY=0 in the environment keeps the copying path (A/B).  NULL on failure. */
 void* alacgpu_alloc_pinned(size_t bytes);
 void alacgpu_free_pinned(void* p);
 
