@@ -40,25 +40,7 @@ template <int CTRL>
 __device__ __forceinline__ int dpp0(int v) {  // out-of-row / invalid source lanes read 0
     return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
 }
-constexpr int DPP_QUAD_1032 = 0xB1, DPP_QUAD_2301 = 0x4E, DPP_ROW_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140;
-constexpr int DPP_ROW_SHL1 = 0x101, DPP_ROW_SHL2 = 0x102, DPP_ROW_SHL4 = 0x104, DPP_ROW_SHL8 = 0x108;
-constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_ROR1 = 0x121;
-
-__device__ __forceinline__ int row_allreduce_add(int v) {
-    v = wadd(v, dpp0<DPP_QUAD_1032>(v));
-    v = wadd(v, dpp0<DPP_QUAD_2301>(v));
-    v = wadd(v, dpp0<DPP_ROW_HALF_MIRROR>(v));
-    v = wadd(v, dpp0<DPP_ROW_MIRROR>(v));
-    return v;
-}
-// inclusive suffix sum inside the row: lane l gets sum over lanes l..15
-__device__ __forceinline__ int row_suffix_scan(int v) {
-    v = wadd(v, dpp0<DPP_ROW_SHL1>(v));
-    v = wadd(v, dpp0<DPP_ROW_SHL2>(v));
-    v = wadd(v, dpp0<DPP_ROW_SHL4>(v));
-    v = wadd(v, dpp0<DPP_ROW_SHL8>(v));
-    return v;
-}
+constexpr int DPP_QUAD_1032 = 0xB1, DPP_QUAD_2301 = 0x4E, DPP_ROW_SHL1 = 0x101, DPP_ROW_SHR1 = 0x111;
 
 // ---- slow-path bit access straight from global memory (header, shift bytes, escape samples) ----
 // `limit` is the packet's readable byte count from `base` (Meta::limit): bytes at or past it read as ZERO, exactly like
@@ -117,23 +99,6 @@ struct Rice {
     uint32_t nforce;      // ~0 when the lane may take the fast step, 0 when it needs the generic one
                           // (inside a zero run, or signModifier pending)
 };
-
-// ---- single-instruction helpers the compiler does not pick by itself --------------------------------
-__device__ __forceinline__ uint32_t ffbh_u32(uint32_t x) {  // count leading zeros; 0xFFFFFFFF for x == 0
-    uint32_t r;
-    asm("v_ffbh_u32 %0, %1" : "=v"(r) : "v"(x));
-    return r;
-}
-__device__ __forceinline__ uint32_t bfm0(uint32_t k) {  // (1 << k) - 1
-    uint32_t r;
-    asm("v_bfm_b32 %0, %1, 0" : "=v"(r) : "v"(k));
-    return r;
-}
-__device__ __forceinline__ uint32_t and_not(uint32_t b, uint32_t m) {  // b & ~m
-    uint32_t r;
-    asm("v_bfi_b32 %0, %1, 0, %2" : "=v"(r) : "v"(m), "v"(b));
-    return r;
-}
 
 // The cursor that goes with `rem` unconsumed bits in w0 and w2 at LDS address ra.
 __device__ __forceinline__ uint32_t rice_cursor(int rem, uint32_t ra) {

@@ -6,6 +6,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -52,7 +54,9 @@ struct alacgpu_ctx {
     int dense = -1;                    // main kernel's 16-packet workgroups: -1 auto (by batch size), 0 never, 1 always (ALACGPU_DENSE; A/B and tests)
                                        // 2 / 3 / 4 (ALACGPU_DENSE=..): never, and the 96-register build / the 16-step-unit build / the plain
                                        // 128-register build of the 8-packet arrangement whatever the batch size (tests)
-    uint32_t* d_cu_arrivals = nullptr; // per-CU workgroup counters (alac_decode_params::cu_arrivals)
+    uint32_t* d_cu_arrivals = nullptr; // per-CU workgroup counters (alac_decode_params::cu_arrivals): ONE array per device, shared by
+                                       // every context of the process on it (cu_counters_acquire), so that launches of different
+                                       // contexts take their turns on a CU from the same counter
     bool zero_copy = true;             // host-buffer entry points store straight into page-locked output (ALACGPU_ZERO_COPY=0: A/B)
     // grow-only device workspace for the host-buffer entry points
     void* d_ws = nullptr;
@@ -73,6 +77,32 @@ namespace {
     } while (0)
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// The per-CU turn counters of a device (see alac_decode_params::cu_arrivals), reference-counted per process: two contexts on
+// one GPU -- two-in-flight from two contexts, alacgpu_decode_batch_sharded rehearsed on one device -- must not each believe
+// that they alternate the SIMD roles alone.
+struct cu_counters { uint32_t* d = nullptr; int refs = 0; };
+std::mutex g_cu_mutex;
+std::map<int, cu_counters> g_cu_by_device;
+uint32_t* cu_counters_acquire(int device) {   // (the caller has made `device` current)
+    std::lock_guard<std::mutex> lock(g_cu_mutex);
+    cu_counters& c = g_cu_by_device[device];
+    if (!c.d) {
+        if (hipMalloc((void**)&c.d, 2048 * sizeof(uint32_t)) != hipSuccess) { c.d = nullptr; return nullptr; }
+        if (hipMemset(c.d, 0, 2048 * sizeof(uint32_t)) != hipSuccess) { (void)hipFree(c.d); c.d = nullptr; return nullptr; }
+    }
+    c.refs++;
+    return c.d;
+}
+void cu_counters_release(int device) {
+    std::lock_guard<std::mutex> lock(g_cu_mutex);
+    auto it = g_cu_by_device.find(device);
+    if (it == g_cu_by_device.end()) return;
+    if (--it->second.refs <= 0) {
+        if (it->second.d) (void)hipFree(it->second.d);
+        g_cu_by_device.erase(it);
+    }
+}
 
 int ensure_ws(alacgpu_ctx* ctx, size_t bytes) {
     if (bytes <= ctx->ws_bytes) return ALACGPU_OK;
@@ -274,8 +304,7 @@ int alacgpu_create(const alacgpu_cfg* cfgs, uint32_t n_cfgs, int device, alacgpu
         // (the other streams of the host-buffer pipeline, the launch slots' events and the workspace are made on first use:
         // a context per file -- the reference's AlacContext -- should cost next to nothing to open)
         if (hipStreamCreateWithFlags(&ctx->streams[0], hipStreamNonBlocking) != hipSuccess) { rc = ALACGPU_ERR_HIP; break; }
-        if (hipMalloc((void**)&ctx->d_cu_arrivals, 2048 * sizeof(uint32_t)) != hipSuccess ||
-            hipMemset(ctx->d_cu_arrivals, 0, 2048 * sizeof(uint32_t)) != hipSuccess) { rc = ALACGPU_ERR_HIP; break; }
+        if (!(ctx->d_cu_arrivals = cu_counters_acquire(device))) { rc = ALACGPU_ERR_HIP; break; }
     } while (0);
     if (rc != ALACGPU_OK) {
         alacgpu_destroy(ctx);
@@ -298,7 +327,7 @@ void alacgpu_destroy(alacgpu_ctx* ctx) {
         if (sl.ev1) (void)hipEventDestroy(sl.ev1);
     }
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
-    if (ctx->d_cu_arrivals) (void)hipFree(ctx->d_cu_arrivals);
+    if (ctx->d_cu_arrivals) cu_counters_release(ctx->device);
     if (ctx->h_frame) (void)hipHostFree(ctx->h_frame);
     if (ctx->d_cfgs) (void)hipFree(ctx->d_cfgs);
     for (int i = 0; i < N_HOST_STREAMS; i++)
