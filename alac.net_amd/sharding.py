@@ -52,14 +52,17 @@ def shard_batch(blob, offsets, sizes, cfg_idx, rank, world, by_bytes=False):
     return blob, np.ascontiguousarray(offsets[lo:hi]), np.ascontiguousarray(sizes[lo:hi]), ci, (lo, hi)
 
 
-def padded_shard(n_packets, world):
-    """Packets per rank after padding to equal shards (all_gather needs equal counts)."""
+def padded_shard(n_packets, world, first=None):
+    """Packets per rank after padding to equal shards (all_gather needs equal counts): the largest range."""
+    if first is not None:
+        return int(max(int(first[r + 1]) - int(first[r]) for r in range(world)))
     return (n_packets + world - 1) // world
 
 
-def allgather_pcm(local_pcm, n_packets, group=None):
-    """All-gather equal-size PCM shards (torch tensors [per_rank, slot]) and trim the padding.
-    Works with any torch.distributed backend (nccl = RCCL on ROCm, gloo on CPU)."""
+def allgather_pcm(local_pcm, n_packets, group=None, first=None):
+    """All-gather equal-size (padded) PCM shards (torch tensors [per_rank, slot]) and trim the padding.  `first`: the
+    partition (shard_ranges) when it is not the by-count one.  Works with any torch.distributed backend (nccl = RCCL on
+    ROCm, gloo on CPU); the library's own alacgpu_allgather_pcm gathers in place without padding."""
     import torch
     import torch.distributed as dist
 
@@ -67,10 +70,10 @@ def allgather_pcm(local_pcm, n_packets, group=None):
     per = local_pcm.shape[0]
     out = torch.empty((world * per,) + tuple(local_pcm.shape[1:]), dtype=local_pcm.dtype, device=local_pcm.device)
     dist.all_gather_into_tensor(out, local_pcm.contiguous(), group=group)
-    # undo the padding: rank r owns packets shard_range(n_packets, r, world)
+    # undo the padding: rank r owns packets first[r] .. first[r+1] (by count: shard_range(n_packets, r, world))
     parts = []
     for r in range(world):
-        lo, hi = shard_range(n_packets, r, world)
+        lo, hi = (int(first[r]), int(first[r + 1])) if first is not None else shard_range(n_packets, r, world)
         parts.append(out[r * per: r * per + (hi - lo)])
     return torch.cat(parts, dim=0)
 

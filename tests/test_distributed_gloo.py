@@ -50,6 +50,19 @@ def _worker(rank, world, port, n_packets, outdir):
     parts = [full2[r * per: r * per + (sharding.shard_range(n_packets, r, world)[1] - sharding.shard_range(n_packets, r, world)[0])]
              for r in range(world)]
     assert torch.equal(torch.cat(parts, dim=0), full)
+    # the byte-balanced partition (what the library's multi-GPU entry points use): skew the sizes so that it differs from the
+    # by-count one, decode those ranges, gather with the same partition
+    skew = b["sizes"].astype(np.uint64) * np.where(np.arange(n_packets) < n_packets // 2, 1, 7)
+    first = sharding.shard_ranges(skew, world)
+    lo3, hi3 = int(first[rank]), int(first[rank + 1])
+    ci3 = None if b["cfg_idx"] is None else np.ascontiguousarray(b["cfg_idx"][lo3:hi3])
+    pcm3 = orc.decode_batch(orc.make_cfgs(b["stream_cfgs"]), b["blob"], np.ascontiguousarray(b["offsets"][lo3:hi3]),
+                            np.ascontiguousarray(b["sizes"][lo3:hi3]), ci3, b["slot_ints"])[0] if hi3 > lo3 else np.zeros((0, b["slot_ints"]), np.int32)
+    per3 = sharding.padded_shard(n_packets, world, first)
+    local3 = torch.zeros((per3, b["slot_ints"]), dtype=torch.int32)
+    local3[: hi3 - lo3] = torch.from_numpy(pcm3)
+    full3 = sharding.allgather_pcm(local3, n_packets, first=first)
+    assert torch.equal(full3, full)
     if rank == 0:
         ref = orc.decode_batch(orc.make_cfgs(b["stream_cfgs"]), b["blob"], b["offsets"], b["sizes"], b["cfg_idx"],
                                b["slot_ints"])[0]
