@@ -204,7 +204,7 @@ __device__ __forceinline__ int rice_step(Rice& s, const RiceCfg& c, int remainin
 // rice_step.  A lane that has left the common case keeps running on garbage; that is harmless (LDS ring
 // reads are address-masked, nothing else is touched).
 // WANT_R: return the residual (else 0).  RAW: return the unsigned code value dv instead of the signed residual
-// (dv >> 1) ^ -(dv & 1) (:225-226) -- a consumer with cycles to spare does that conversion itself (fir8_step<.., true>).
+// (dv >> 1) ^ -(dv & 1) (:225-226) -- the output wave, which has cycles to spare, does that conversion (xq_from_code).
 // It does not apply the history clamp for values above 0xFFFF either (:229; two instructions): it tracks the largest value
 // in vmax instead, and the caller sends a unit with vmax > 0xFFFF to the escape tier, whose step does clamp.
 template <bool WANT_R, bool RAW = false>

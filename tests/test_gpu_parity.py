@@ -363,7 +363,7 @@ def test_packed_output_equals_format_samples(pkg, oracle, synth, cfg):
 @pytest.mark.parametrize("out_format", [0, 1])
 def test_both_two_pass_kernels_share_a_batch(pkg, oracle, synth, out_format):
     # groups of 8 packets alternate between what the main two-pass kernel takes (orders 1..8, or 16 somewhere in the
-    # group: two taps per lane) and what it hands to the 32-tap kernel behind it (order 24, 31 = delta mode, or 0 somewhere
+    # group: two taps per lane) and what it hands to the four-taps-per-lane code of the second launch (order 24, 31 = delta mode, or 0 somewhere
     # in the group); one-channel, uncompressed and short packets mixed in; the last group is partly filled
     count = 8 * 9 + 5
     rng = np.random.default_rng(4711)
@@ -549,7 +549,7 @@ def test_speculative_tiers_on_full_length_streams(pkg, oracle, synth, is24, cont
 def test_ragged_batches_long_and_short_packets_share_a_workgroup(pkg, oracle, synth, stereo, orders):
     # Most packets are full frames, a few end early at assorted places (chunk boundaries, one sample either side of
     # them, one sample long): in the two-pass kernels a stream that ends becomes a shadow of the longest stream of its wave
-    # and the speculative units go on -- in all three FIR arrangements (one tap per lane, two taps per lane, the 32-tap
+    # and the speculative units go on -- in all three FIR arrangements (one tap per lane, two taps per lane, the four-taps / 16-lane
     # kernel with the delta mode), both passes, and for one-channel packets.
     count = 64
     rng = np.random.default_rng(orders[0] * 7 + stereo)
