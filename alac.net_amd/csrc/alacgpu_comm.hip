@@ -29,6 +29,8 @@ struct rccl_api {
     int (*CommDestroy)(nccl_comm_t) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, nccl_comm_t, hipStream_t) = nullptr;
     int (*Broadcast)(const void*, void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+    int (*Send)(const void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
@@ -54,6 +56,8 @@ rccl_api& rccl() {
         api.CommDestroy = (int (*)(nccl_comm_t))sym("ncclCommDestroy");
         api.AllGather = (int (*)(const void*, void*, size_t, int, nccl_comm_t, hipStream_t))sym("ncclAllGather");
         api.Broadcast = (int (*)(const void*, void*, size_t, int, int, nccl_comm_t, hipStream_t))sym("ncclBroadcast");
+        api.Send = (int (*)(const void*, size_t, int, int, nccl_comm_t, hipStream_t))dlsym(api.handle, "ncclSend");   // (optional)
+        api.Recv = (int (*)(void*, size_t, int, int, nccl_comm_t, hipStream_t))dlsym(api.handle, "ncclRecv");
         api.GroupStart = (int (*)())sym("ncclGroupStart");
         api.GroupEnd = (int (*)())sym("ncclGroupEnd");
         api.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
@@ -93,9 +97,12 @@ namespace {
         }                                                                                        \
     } while (0)
 
-// One in-place all-gather-v of packet ranges [lo_r + a_r, lo_r + b_r) of every rank r (a slot is slot_ints int32): equal
-// counts -> ncclAllGather is not applicable to sub-ranges of unequal shards, so every rank's piece is one broadcast from
-// its owner inside one group (RCCL fuses the group into one launch; pieces travel over different xGMI links at once).
+// One in-place all-gather-v of packet ranges [first_r, first_r + count_r) of every rank r (a slot is slot_ints int32).
+// Equal pieces that lie side by side in rank order are one plain in-place ncclAllGather (RCCL picks the algorithm).  Pieces
+// that do not (unequal shards; the k-th piece of every shard in the overlapped form) are exchanged directly: inside one group
+// every rank sends its piece to every other rank and receives theirs, in place -- on a node whose GPUs are all linked to each
+// other (xGMI: 7 links per GPU) that uses every link at once, the pattern SURVEY.md section 8(e) asks for; grouped broadcasts
+// (one per owner) are the fallback when the library has no ncclSend / ncclRecv.
 int gather_pieces(alacgpu_comm* c, int32_t* d_full, uint32_t slot_ints, const std::vector<uint64_t>& first,
                   const std::vector<uint64_t>& count, hipStream_t s) {
     rccl_api& R = rccl();
@@ -107,11 +114,21 @@ int gather_pieces(alacgpu_comm* c, int32_t* d_full, uint32_t slot_ints, const st
                                  (size_t)count[0] * slot_ints, NCCL_INT32, c->comm, s));
         return ALACGPU_OK;
     }
+    if (c->world == 1) return ALACGPU_OK;   // nothing to exchange
     COMM_NCCL(c, R.GroupStart());
-    for (int r = 0; r < c->world; r++) {
-        if (count[r] == 0) continue;
-        int32_t* piece = d_full + first[r] * slot_ints;
-        COMM_NCCL(c, R.Broadcast(piece, piece, (size_t)count[r] * slot_ints, NCCL_INT32, r, c->comm, s));
+    if (R.Send && R.Recv) {
+        const int me = c->rank;
+        for (int k = 1; k < c->world; k++) {
+            const int to = (me + k) % c->world, from = (me - k + c->world) % c->world;   // (a different peer pair per round)
+            if (count[me]) COMM_NCCL(c, R.Send(d_full + first[me] * slot_ints, (size_t)count[me] * slot_ints, NCCL_INT32, to, c->comm, s));
+            if (count[from]) COMM_NCCL(c, R.Recv(d_full + first[from] * slot_ints, (size_t)count[from] * slot_ints, NCCL_INT32, from, c->comm, s));
+        }
+    } else {
+        for (int r = 0; r < c->world; r++) {
+            if (count[r] == 0) continue;
+            int32_t* piece = d_full + first[r] * slot_ints;
+            COMM_NCCL(c, R.Broadcast(piece, piece, (size_t)count[r] * slot_ints, NCCL_INT32, r, c->comm, s));
+        }
     }
     COMM_NCCL(c, R.GroupEnd());
     return ALACGPU_OK;

@@ -49,6 +49,8 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="single-thread CPU baseline: run at least this long")
     ap.add_argument("--no-allgather", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="N>1: skip the cfg4 / cfg5 extra measurements")
+    ap.add_argument("--extra-timeout", type=int, default=240,
+                    help="N>1: seconds the all-gather + extra measurements may take before the line is printed without them (0: no limit)")
     ap.add_argument("--extra-packets", type=int, default=None, help="packets per GPU of the extra configs (rehearsals)")
     ap.add_argument("--no-host-path", action="store_true", help="N=1: skip the PCIe-inclusive and latency measurements")
     ap.add_argument("--no-big-batch", action="store_true", help="N=1: skip the extra line for a 32768-packet batch of the same config")
@@ -412,109 +414,10 @@ def main():
     gather_via = None
     extra = {}
     extra_error = None
-    # (the headline measurement above is complete at this point; a failure below -- out of memory, a collective that the
-    # node's fabric refuses -- is reported in the line as "extra_error" instead of taking `value` down with it)
-    try:
-        if distributed and not args.no_allgather:
-            allgather_ms, overlapped_ms, gather_ok, gather_via = gather_figures(pkg, torch, dist, sharding, np, w, world, rank, dev, cdev,
-                                                                                 args.backend)
-        if distributed and not args.no_extra:
-            for cfgno in (4, 5):
-                if cfgno == args.config:
-                    continue
-                npk = args.extra_packets or PER_GPU_PACKETS[cfgno]
-                we = Workload(pkg, synth, torch, np, cfgno, npk, rank, dev, local_rank)
-                ksteps = max(1, min(args.steps, 10))
-                el, kms = timed_steps(torch, dist, we, ksteps, min(args.warmup, 2), dev, True)
-                ok = we.status_ok()
-                el, kms = reduce_max(torch, dist, cdev, el, kms)
-                tot, ab, bad = reduce_sum(torch, dist, cdev, we.samples, we.algo_bytes, 0 if ok else 1)
-                row = {"workload": NAMES[cfgno], "packets_per_gpu": npk, "steps": ksteps,
-                       "value": round(tot * ksteps / el / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(el / ksteps * 1e3, 4),
-                       "kernel_ms": round(kms, 4), "roofline_frac": round(we.algo_bytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                       "status_ok": bad == 0}
-                if not args.no_allgather:
-                    a_ms, o_ms, g_ok, _ = gather_figures(pkg, torch, dist, sharding, np, we, world, rank, dev, cdev, args.backend)
-                    a_ms, o_ms = reduce_max(torch, dist, cdev, a_ms, o_ms)
-                    row.update(allgather_ms=round(a_ms, 4), decode_allgather_overlapped_ms=round(o_ms, 4),
-                               allgather_bytes_per_rank=int(we.d_pcm.numel() * 4))
-                    gather_ok = gather_ok and g_ok
-                status_ok = status_ok and bad == 0
-                extra[f"cfg{cfgno}"] = row
-                we.close()
-                del we
-    except Exception as e:   # noqa: BLE001
-        extra_error = f"{type(e).__name__}: {e}"[:400]
-    if distributed and extra_error is None:
-        try:
-            (gbad,) = reduce_sum(torch, dist, cdev, 0 if gather_ok else 1)
-            gather_ok = gbad == 0
-            if allgather_ms is not None:
-                allgather_ms, overlapped_ms = reduce_max(torch, dist, cdev, allgather_ms, overlapped_ms)
-        except Exception as e:   # noqa: BLE001
-            extra_error = f"{type(e).__name__}: {e}"[:400]
+    cpu_baseline = parity = host_path = big_batch = None
 
-    # ---- correctness + CPU baseline (rank 0, N=1 only; the oracle is the checker, never the product) ----
-    b = w.b
-    cpu_baseline = None
-    parity = None
-    host_path = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        import alac_oracle_py as orc
-
-        cfgs = orc.make_cfgs(b["stream_cfgs"])
-        allcores = sorted(os.sched_getaffinity(0))
-        ncores = len(allcores)
-        # whole batch on all cores: the parity reference
-        t1 = time.perf_counter()
-        refall = orc.decode_batch(cfgs, b["blob"], b["offsets"], b["sizes"], b["cfg_idx"], w.slot, n_threads=ncores)
-        cpuall_s = time.perf_counter() - t1
-        got = w.d_pcm.cpu().numpy()
-        st = w.d_st.cpu().numpy()
-        # every packet's own n * channels ints (what a slot holds beyond them is scratch by contract, include/alacgpu.h)
-        ci_h = np.zeros(n_packets, dtype=np.int64) if b["cfg_idx"] is None else b["cfg_idx"].astype(np.int64)
-        nc_h = np.array([int(c[5]) for c in b["stream_cfgs"]], dtype=np.int64)[ci_h]
-        cnt_h = np.where(refall[3] == 0, refall[2].astype(np.int64) * nc_h, 0)
-        mask = np.arange(w.slot, dtype=np.int64)[None, :] < cnt_h[:, None]
-        parity = bool(np.array_equal(st, refall[3]) and np.array_equal(got[mask], refall[0][mask])
-                      and np.array_equal(w.d_ob.cpu().numpy(), refall[1]) and np.array_equal(w.d_os.cpu().numpy(), refall[2]))
-        # single thread, pinned to one core, the same batch over and over for >= --cpu-seconds
-        os.sched_setaffinity(0, {allcores[len(allcores) // 2]})
-        try:
-            reps, t1 = 0, time.perf_counter()
-            while True:
-                orc.decode_batch(cfgs, b["blob"], b["offsets"], b["sizes"], b["cfg_idx"], w.slot, n_threads=1)
-                reps += 1
-                cpu1_s = time.perf_counter() - t1
-                if cpu1_s >= args.cpu_seconds:
-                    break
-        finally:
-            os.sched_setaffinity(0, set(allcores))
-        cpu_baseline = {
-            "value": round(w.samples * reps / cpu1_s / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
-            "sample": f"the same {n_packets}-packet batch decoded {reps} times ({cpu1_s:.1f} s) by the C restatement of "
-                      f"AlacFile.DecodeFrame (oracle/alac_oracle.c; C# runtime unavailable), 1 thread pinned to one core",
-            "all_cores_value": round(w.samples / cpuall_s / 1e6, 3), "all_cores": ncores,
-        }
-    if rank == 0 and world == 1 and not args.no_host_path:
-        host_path = measure_host_path(pkg, np, w)
-    # ---- the same config in a batch big enough to fill the chip (never `value`: BASELINE quotes the metric on 4096 packets) ----
-    big_batch = None
-    if rank == 0 and world == 1 and not args.no_big_batch and args.packets is None and args.config == 2:
-        try:
-            wb = Workload(pkg, synth, torch, np, args.config, 32768, 0, dev, local_rank)
-            el, kms = timed_steps(torch, dist, wb, 10, 3, dev, False)
-            big_batch = {"packets": 32768, "steps": 10, "value": round(wb.samples * 10 / el / 1e6, 3), "unit": "Msamples/s",
-                         "kernel": "alac_decode_ab_dense_kernel", "kernel_ms": round(kms, 4),
-                         "roofline_frac": round(wb.algo_bytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "status_ok": wb.status_ok(),
-                         "note": "the main kernel's 16-packets-per-workgroup arrangement (batches above 12288 packets); "
-                                 "bound by VALU issue, not by one packet's serial chain"}
-            wb.close()
-            del wb
-        except Exception as e:   # noqa: BLE001
-            big_batch = {"error": f"{type(e).__name__}: {e}"[:300]}
-
-    if rank == 0:
+    def emit():
+        """rank 0's JSON line from whatever has been measured so far."""
         # the main kernel's build by batch size (alacgpu_api.hip: launch): 16-step units up to 4096 packets, 8-step units with 128
         # registers up to 10240, with 96 registers up to 12288, 16 packets per workgroup above
         first = ("alac_decode_ab_small_kernel" if n_packets <= 4096 else "alac_decode_ab_kernel" if n_packets <= 10240
@@ -585,6 +488,124 @@ def main():
         if in_flight:
             line["two_in_flight"] = in_flight
         print(json.dumps(line), flush=True)
+
+    # a collective that never returns (a fabric or library fault on a node this code has never met) must not take the headline
+    # with it: past --extra-timeout seconds rank 0 prints the line it has and every rank leaves
+    watchdog = None
+    if distributed and args.extra_timeout > 0:
+        import threading
+
+        def give_up():
+            nonlocal extra_error
+            extra_error = f"the multi-GPU extras did not finish within {args.extra_timeout} s; line printed without them"
+            if rank == 0:
+                emit()
+            os._exit(3)
+        watchdog = threading.Timer(args.extra_timeout + (0 if rank == 0 else 15), give_up)
+        watchdog.daemon = True
+        watchdog.start()
+    # (the headline measurement above is complete at this point; a failure below -- out of memory, a collective that the
+    # node's fabric refuses -- is reported in the line as "extra_error" instead of taking `value` down with it)
+    try:
+        if distributed and not args.no_allgather:
+            allgather_ms, overlapped_ms, gather_ok, gather_via = gather_figures(pkg, torch, dist, sharding, np, w, world, rank, dev, cdev,
+                                                                                 args.backend)
+        if distributed and not args.no_extra:
+            for cfgno in (4, 5):
+                if cfgno == args.config:
+                    continue
+                npk = args.extra_packets or PER_GPU_PACKETS[cfgno]
+                we = Workload(pkg, synth, torch, np, cfgno, npk, rank, dev, local_rank)
+                ksteps = max(1, min(args.steps, 10))
+                el, kms = timed_steps(torch, dist, we, ksteps, min(args.warmup, 2), dev, True)
+                ok = we.status_ok()
+                el, kms = reduce_max(torch, dist, cdev, el, kms)
+                tot, ab, bad = reduce_sum(torch, dist, cdev, we.samples, we.algo_bytes, 0 if ok else 1)
+                row = {"workload": NAMES[cfgno], "packets_per_gpu": npk, "steps": ksteps,
+                       "value": round(tot * ksteps / el / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(el / ksteps * 1e3, 4),
+                       "kernel_ms": round(kms, 4), "roofline_frac": round(we.algo_bytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                       "status_ok": bad == 0}
+                if not args.no_allgather:
+                    a_ms, o_ms, g_ok, _ = gather_figures(pkg, torch, dist, sharding, np, we, world, rank, dev, cdev, args.backend)
+                    a_ms, o_ms = reduce_max(torch, dist, cdev, a_ms, o_ms)
+                    row.update(allgather_ms=round(a_ms, 4), decode_allgather_overlapped_ms=round(o_ms, 4),
+                               allgather_bytes_per_rank=int(we.d_pcm.numel() * 4))
+                    gather_ok = gather_ok and g_ok
+                status_ok = status_ok and bad == 0
+                extra[f"cfg{cfgno}"] = row
+                we.close()
+                del we
+    except Exception as e:   # noqa: BLE001
+        extra_error = f"{type(e).__name__}: {e}"[:400]
+    if distributed and extra_error is None:
+        try:
+            (gbad,) = reduce_sum(torch, dist, cdev, 0 if gather_ok else 1)
+            gather_ok = gbad == 0
+            if allgather_ms is not None:
+                allgather_ms, overlapped_ms = reduce_max(torch, dist, cdev, allgather_ms, overlapped_ms)
+        except Exception as e:   # noqa: BLE001
+            extra_error = f"{type(e).__name__}: {e}"[:400]
+
+    # ---- correctness + CPU baseline (rank 0, N=1 only; the oracle is the checker, never the product) ----
+    b = w.b
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import alac_oracle_py as orc
+
+        cfgs = orc.make_cfgs(b["stream_cfgs"])
+        allcores = sorted(os.sched_getaffinity(0))
+        ncores = len(allcores)
+        # whole batch on all cores: the parity reference
+        t1 = time.perf_counter()
+        refall = orc.decode_batch(cfgs, b["blob"], b["offsets"], b["sizes"], b["cfg_idx"], w.slot, n_threads=ncores)
+        cpuall_s = time.perf_counter() - t1
+        got = w.d_pcm.cpu().numpy()
+        st = w.d_st.cpu().numpy()
+        # every packet's own n * channels ints (what a slot holds beyond them is scratch by contract, include/alacgpu.h)
+        ci_h = np.zeros(n_packets, dtype=np.int64) if b["cfg_idx"] is None else b["cfg_idx"].astype(np.int64)
+        nc_h = np.array([int(c[5]) for c in b["stream_cfgs"]], dtype=np.int64)[ci_h]
+        cnt_h = np.where(refall[3] == 0, refall[2].astype(np.int64) * nc_h, 0)
+        mask = np.arange(w.slot, dtype=np.int64)[None, :] < cnt_h[:, None]
+        parity = bool(np.array_equal(st, refall[3]) and np.array_equal(got[mask], refall[0][mask])
+                      and np.array_equal(w.d_ob.cpu().numpy(), refall[1]) and np.array_equal(w.d_os.cpu().numpy(), refall[2]))
+        # single thread, pinned to one core, the same batch over and over for >= --cpu-seconds
+        os.sched_setaffinity(0, {allcores[len(allcores) // 2]})
+        try:
+            reps, t1 = 0, time.perf_counter()
+            while True:
+                orc.decode_batch(cfgs, b["blob"], b["offsets"], b["sizes"], b["cfg_idx"], w.slot, n_threads=1)
+                reps += 1
+                cpu1_s = time.perf_counter() - t1
+                if cpu1_s >= args.cpu_seconds:
+                    break
+        finally:
+            os.sched_setaffinity(0, set(allcores))
+        cpu_baseline = {
+            "value": round(w.samples * reps / cpu1_s / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": f"the same {n_packets}-packet batch decoded {reps} times ({cpu1_s:.1f} s) by the C restatement of "
+                      f"AlacFile.DecodeFrame (oracle/alac_oracle.c; C# runtime unavailable), 1 thread pinned to one core",
+            "all_cores_value": round(w.samples / cpuall_s / 1e6, 3), "all_cores": ncores,
+        }
+    if rank == 0 and world == 1 and not args.no_host_path:
+        host_path = measure_host_path(pkg, np, w)
+    # ---- the same config in a batch big enough to fill the chip (never `value`: BASELINE quotes the metric on 4096 packets) ----
+    if rank == 0 and world == 1 and not args.no_big_batch and args.packets is None and args.config == 2:
+        try:
+            wb = Workload(pkg, synth, torch, np, args.config, 32768, 0, dev, local_rank)
+            el, kms = timed_steps(torch, dist, wb, 10, 3, dev, False)
+            big_batch = {"packets": 32768, "steps": 10, "value": round(wb.samples * 10 / el / 1e6, 3), "unit": "Msamples/s",
+                         "kernel": "alac_decode_ab_dense_kernel", "kernel_ms": round(kms, 4),
+                         "roofline_frac": round(wb.algo_bytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "status_ok": wb.status_ok(),
+                         "note": "the main kernel's 16-packets-per-workgroup arrangement (batches above 12288 packets); "
+                                 "bound by VALU issue, not by one packet's serial chain"}
+            wb.close()
+            del wb
+        except Exception as e:   # noqa: BLE001
+            big_batch = {"error": f"{type(e).__name__}: {e}"[:300]}
+
+    if watchdog:
+        watchdog.cancel()
+    if rank == 0:
+        emit()
     w.close()
     if distributed:
         try:
