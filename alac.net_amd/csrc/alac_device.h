@@ -155,6 +155,10 @@ struct RiceCfg {
     uint32_t kmask;
     int hist_mult;
     int rss;
+    // derived (rice_cfg_finish), for the plain speculative step:
+    uint32_t keep_mult;    // 512 - hist_mult
+    uint32_t keep_bias;    // 1536 * hist_mult + 511
+    int cfloor;            // the smallest clz(history + 1536) the plain step is exact for
 };
 
 // The "compressed blocks of 0" branch of EntropyRiceDecode (AlacFile.cs:231-249), taken right after a
@@ -205,10 +209,71 @@ __device__ __forceinline__ int rice_step(Rice& s, const RiceCfg& c, int remainin
 // reads are address-masked, nothing else is touched).
 // WANT_R: return the residual (else 0).  RAW: return the unsigned code value dv instead of the signed residual
 // (dv >> 1) ^ -(dv & 1) (:225-226) -- the output wave, which has cycles to spare, does that conversion (xq_from_code).
-// It does not apply the history clamp for values above 0xFFFF either (:229; two instructions): it tracks the largest value
-// in vmax instead, and the caller sends a unit with vmax > 0xFFFF to the escape tier, whose step does clamp.
+// What the plain step leaves out, and how the caller finds out (rice_plain_ok) that nothing was missed:
+//  * s.hist holds H = history + 1536 while the plain steps run (the caller adds and removes the bias): k = 22 - clz(H)
+//    without the addition, and history - ((history * mult) >> 9) is one 24-bit multiply-add and a shift (c.keep_mult = 512 -
+//    mult, c.keep_bias = 1536 * mult + 511) -- exact while H < 2^23 (the sum stays below 2^32) and history * mult < 2^31
+//    (the reference's product does not wrap);
+//  * k is not capped at kmod (:222), the history clamp for values above 0xFFFF (:229) is not applied: the step tracks the
+//    smallest clz(H) of the unit in cmin instead.  cmin >= c.cfloor says that no k of the unit was above kmod (and that H
+//    stayed inside the exact range above); with the unit's largest prefix xmax, (xmax + 1) << (22 - cmin) <= 65536 says that no
+//    value was above 0xFFFF (a value is below (x + 1) << k).  A unit that fails either test goes to the escape tier, whose
+//    step caps and clamps.
 template <bool WANT_R, bool RAW = false>
 __device__ __forceinline__ int rice_spec_step(Rice& s, const RiceCfg& c, uint32_t ring, uint32_t& xmax,
+                                              int& hmin, uint32_t& cmin) {
+    const uint32_t win = rice_window(s);
+    const uint32_t x = (uint32_t)__builtin_clz(~win | 0x00400000u);          // leading ones, capped at 9 (:196)
+    xmax = max(xmax, x);
+    const uint32_t H = (uint32_t)s.hist;                                     // history + 1536
+    // (hist >> 9) + 3 == (hist + 1536) >> 9 for hist >= 0, so 31 - clz((hist >> 9) + 3) = 22 - clz(H)    (:221)
+    const uint32_t lz = (uint32_t)__builtin_clz(H);
+    cmin = min(cmin, lz);
+    int k = 22 - (int)lz;
+    asm("" : "+v"(k));                  // (keeps x + k one sum used twice: the compiler otherwise spreads 22 - lz over both uses)
+    uint32_t xk = x + (uint32_t)k;
+    asm("" : "+v"(xk));
+    const uint32_t e = __builtin_amdgcn_ubfe(win, 31u - xk, (uint32_t)k);          // Readbits(k) (:205)
+    const uint32_t m = __builtin_amdgcn_ubfe(0xFFFFFFFFu, 0u, (uint32_t)k);        // (1 << k) - 1
+    const uint32_t v = __umul24(x, m) + (e > 1u ? e - 1u : 0u);                    // :206-208
+    const uint32_t cur2 = s.cur - xk - (e > 1u ? 1u : 0u);                   // bits used: x+1+k, minus the un-read one (:210)
+    int r = 0;
+    if (WANT_R) r = RAW ? (int)v : (int)(v >> 1) ^ -(int)(v & 1u);           // :225-226
+    // H - ((history * mult) >> 9) = ceil((512 H - history * mult) / 512) = (H * (512 - mult) + 1536 * mult + 511) >> 9
+    const uint32_t kept = (__umul24(H, c.keep_mult) + c.keep_bias) >> 9;
+    const int hn = (int)(__umul24(v, (uint32_t)c.hist_mult) + kept);         // :229 without the clamp, still biased
+    hmin = min(hmin, hn);
+    const uint32_t a2 = rice_w2_addr(cur2, ring);
+    const bool adv = a2 != s.ra;
+    s.cur = cur2;
+    s.w0 = adv ? s.w1 : s.w0;
+    s.w1 = adv ? s.w2 : s.w1;
+    s.ra = a2;
+    s.w2 = lds_load(a2);
+    s.hist = hn;
+    return r;
+}
+constexpr int RICE_PLAIN_BIAS = 1536;
+// The verdict on a unit of narrow plain steps, per lane, escape codes aside: no value above 0xFFFF, no k above kmod, history
+// inside the exact range (see rice_spec_step).
+__device__ __forceinline__ bool rice_narrow_ok(const RiceCfg& c, uint32_t xmax, uint32_t cmin) {
+    const uint32_t kmax = (22u - cmin) & 31u;
+    return cmin >= (uint32_t)c.cfloor && cmin <= 22u && ((xmax + 1u) << kmax) <= 0x10000u;
+}
+// The derived members of RiceCfg.
+__device__ __forceinline__ void rice_cfg_finish(RiceCfg& c) {
+    // hist_mult = ricemodifier (3 bits) * (rice_history_mult (a byte) / 4) <= 441 < 512
+    c.keep_mult = 512u - (uint32_t)c.hist_mult;
+    c.keep_bias = (uint32_t)RICE_PLAIN_BIAS * (uint32_t)c.hist_mult + 511u;
+    const int mbits = 32 - __builtin_clz((uint32_t)c.hist_mult | 1u);        // hist_mult < 2^mbits
+    c.cfloor = max(max(9, mbits + 1), 22 - c.kmod);
+}
+// The plain step for every history and every kmod (streams the narrow step's arithmetic does not hold: k at its cap, history
+// + 1536 >= 2^23 -- full-scale noise): k capped (:222), the decay term by a full 32-bit multiply.  It leaves out the history
+// clamp for values above 0xFFFF (:229; two instructions) and tracks the largest value in vmax instead; the caller sends a unit
+// with vmax > 0xFFFF to the escape tier, whose step does clamp.
+template <bool WANT_R, bool RAW = false>
+__device__ __forceinline__ int rice_spec_step_wide(Rice& s, const RiceCfg& c, uint32_t ring, uint32_t& xmax,
                                               int& hmin, uint32_t& vmax) {
     const uint32_t win = rice_window(s);
     const uint32_t x = (uint32_t)__builtin_clz(~win | 0x00400000u);          // leading ones, capped at 9 (:196)

@@ -7,6 +7,7 @@
 //   [4] zero-run tier units << 32 | escape tier units
 //   [5] plain units failed by a new run symbol << 48 | units redone by the generic step << 32
 //   [6] full tier units << 48 | late run failures << 32
+//   [7] units of the wide plain step << 32 | narrow plain units failed by their range (history / k / value bound)
 //   [3] HW_ID of wave 0 | XCC_ID << 32
 #ifndef ALAC_DIAG_H
 #define ALAC_DIAG_H
@@ -14,6 +15,7 @@
 #ifdef ALAC_DIAG
 struct SpecStats {
     int plain_ok = 0, fail_esc = 0, fail_run = 0, z_units = 0, esc_units = 0, full_units = 0, late_run = 0, redo = 0;
+    int fail_range = 0, wide_units = 0;
 };
 #define SPEC_COUNT(field) (st.field++)
 #define DIAG_ONLY(...) __VA_ARGS__

@@ -86,7 +86,20 @@ constexpr int ESC_HOLD = ALAC_ESC_HOLD;
 #ifndef ALAC_ESC_LONG
 #define ALAC_ESC_LONG 1
 #endif
+// Streams beyond the narrow plain step's arithmetic (rice_spec_step: full-scale noise) stay on the wide plain step for WIDE_HOLD
+// units at a time.
+#ifndef ALAC_WIDE_HOLD
+#define ALAC_WIDE_HOLD 32
+#endif
+// ALAC_NARROW=0 leaves the narrow step out (the wide one is then THE plain step).  The small-batch build does: at <= 4096
+// packets a launch is as long as its slowest workgroup, which sits on the escape tier most of the time, and the extra tier's
+// code costs that workgroup more than its few plain units gain (cfg2 at 4096 packets: 0.693 -> 0.698 ms with it).
+#ifndef ALAC_NARROW
+#define ALAC_NARROW 1
+#endif
+constexpr bool NARROW_PLAIN = ALAC_NARROW != 0;
 struct TierState {
+    int wide;        // units still to decode with the wide plain step
     int full_left;   // units still to decode on an escape-capable tier
     int hold;        // clean units the escape tier waits for before handing back to the plain tier
     int since;       // units since the last escape code
@@ -130,30 +143,67 @@ __device__ __forceinline__ bool spec_unit(Rice& rs, TierState& ts, const RiceCfg
     // back afterwards, minus SPEC_UNIT zeros: one silent stream does not keep the other seven on tier 2.
     const bool parked = rs.zrun >= SPEC_UNIT;
     const bool special = __builtin_amdgcn_ballot_w64(rs.nforce == 0u && !parked) != 0;
-    uint32_t xmax = 0, vmax = 0;
+    uint32_t xmax = 0;
     int hmin = 0x7FFFFFFF;
     int acc[4] = {0, 0, 0, 0};
     if (ts.full_left == 0) {
-        if (!special) {
+        bool newrun = false, sawesc = false;
+        bool wide = !NARROW_PLAIN || ts.wide > 0;
+        if (NARROW_PLAIN && __builtin_expect(!special && !wide, 1)) {
+            // the narrow plain step (rice_spec_step): the hot path of the whole kernel
+            uint32_t cmin = 32;
+            rs.hist += RICE_PLAIN_BIAS;            // (the narrow step's form of the history)
 #pragma unroll
             for (int ii = 0; ii < SPEC_UNIT; ii++) {
-                const int r = rice_spec_step<WANT_R, RAW>(rs, c, ring, xmax, hmin, vmax);
+                const int r = rice_spec_step<WANT_R, RAW>(rs, c, ring, xmax, hmin, cmin);
+                if (WANT_R) spec_store<QSTRIDE>(q, ii, acc, r);
+            }
+            rs.hist -= RICE_PLAIN_BIAS;
+            hmin -= RICE_PLAIN_BIAS;
+            spec_unpark<WANT_R, QSTRIDE>(rs, snap, parked, xmax, hmin, q);
+            newrun = __builtin_amdgcn_ballot_w64(hmin < 128) != 0;
+            // an escape code -- or a history, a k or a value beyond the narrow step's arithmetic
+            sawesc = __builtin_amdgcn_ballot_w64(xmax > 8u || (!parked && !rice_narrow_ok(c, xmax, cmin))) != 0;
+            if (__builtin_expect(!newrun && !sawesc, 1)) { SPEC_COUNT(plain_ok); ts.since++; return true; }
+            // no escape code, then: the same unit again with the wide plain step (what the narrow one made of such a stream's
+            // history means nothing: no verdict on runs from it)
+            if (sawesc && __builtin_amdgcn_ballot_w64(xmax > 8u) == 0) {
+                rs = snap;
+                xmax = 0;
+                hmin = 0x7FFFFFFF;
+                ts.wide = ALAC_WIDE_HOLD;
+                wide = true;
+                SPEC_COUNT(fail_range);
+            }
+        }
+        if (!special && wide) {
+            uint32_t vmax = 0;
+#pragma unroll
+            for (int ii = 0; ii < SPEC_UNIT; ii++) {
+                const int r = rice_spec_step_wide<WANT_R, RAW>(rs, c, ring, xmax, hmin, vmax);
                 if (WANT_R) spec_store<QSTRIDE>(q, ii, acc, r);
             }
             spec_unpark<WANT_R, QSTRIDE>(rs, snap, parked, xmax, hmin, q);
-            vmax = parked ? 0u : vmax;
-        } else {
+            newrun = __builtin_amdgcn_ballot_w64(hmin < 128) != 0;
+            // an escape code -- or a value whose history update needs the clamp the plain steps leave out
+            sawesc = __builtin_amdgcn_ballot_w64(xmax > 8u || (!parked && vmax > 0xFFFFu)) != 0;
+            // back to the narrow step once every stream is well inside its range again (looked at every WIDE_HOLD units)
+            if (NARROW_PLAIN && --ts.wide == 0 &&
+                __builtin_amdgcn_ballot_w64(!parked && __builtin_clz((uint32_t)rs.hist + RICE_PLAIN_BIAS) <= c.cfloor) != 0)
+                ts.wide = ALAC_WIDE_HOLD;
+            if (NARROW_PLAIN) SPEC_COUNT(wide_units);
+            if (__builtin_expect(!newrun && !sawesc, 1)) { if (!NARROW_PLAIN) SPEC_COUNT(plain_ok); ts.since++; return true; }
+        } else if (special) {
 #pragma unroll
             for (int ii = 0; ii < SPEC_UNIT; ii++) {
                 const int r = rice_spec_step_z<WANT_R, RAW>(rs, c, ring, xmax, hmin);
                 if (WANT_R) spec_store<QSTRIDE>(q, ii, acc, r);
             }
             rs.nforce = (rs.zrun > 0 || rs.signmod != 0) ? 0u : 0xFFFFFFFFu;
+            newrun = __builtin_amdgcn_ballot_w64(hmin < 128) != 0;
+            sawesc = __builtin_amdgcn_ballot_w64(xmax > 8u) != 0;
+            if (__builtin_expect(!newrun && !sawesc, 1)) { SPEC_COUNT(z_units); ts.since++; return true; }
         }
-        const bool newrun = __builtin_amdgcn_ballot_w64(hmin < 128) != 0;
-        // an escape code -- or a value whose history update needs the clamp the plain step leaves out
-        const bool sawesc = __builtin_amdgcn_ballot_w64(xmax > 8u || vmax > 0xFFFFu) != 0;
-        if (__builtin_expect(!newrun && !sawesc, 1)) { if (special) SPEC_COUNT(z_units); else SPEC_COUNT(plain_ok); ts.since++; return true; }
         rs = snap;
         if (newrun) { SPEC_COUNT(fail_run); return false; }          // no tier can do it
         SPEC_COUNT(fail_esc);
@@ -287,6 +337,7 @@ __device__ __forceinline__ uint32_t ab_entropy_pass(const alac_decode_params& p,
     // every stream's first value is coded against the initial history (a small k): as a rule an escape code -- the pass
     // starts on the escape tier instead of failing its first plain unit
     TierState ts;
+    ts.wide = 0;
     ts.full_left = 1;
     ts.hold = ESC_HOLD;
     ts.since = ALAC_ESC_NEAR;
@@ -312,6 +363,7 @@ __device__ __forceinline__ uint32_t ab_entropy_pass(const alac_decode_params& p,
     mc.kmask = (1u << (mc.kmod & 31)) - 1u;      // (1 << kb) - 1 with C#'s five-bit shift count (AlacFile.cs:483)
     mc.hist_mult = mirror_i(rc.hist_mult, src);
     mc.rss = mirror_i(rc.rss, src);
+    rice_cfg_finish(mc);
     int n_eff = mirror_i(m.n, src);
     const int ih = mirror_i(init_hist, src);
     const uint32_t sb = (uint32_t)mirror_i((int)startbit, src);
@@ -485,6 +537,7 @@ __device__ __forceinline__ void ab_entropy_wave(const alac_decode_params& p, uin
         d[4] = ((unsigned long long)st.z_units << 32) | (unsigned)st.esc_units;
         d[5] = ((unsigned long long)st.fail_run << 48) | ((unsigned long long)st.redo << 32);
         d[6] = ((unsigned long long)st.full_units << 48) | ((unsigned long long)st.late_run << 32);
+        d[7] = ((unsigned long long)st.wide_units << 32) | (unsigned)st.fail_range;
         d[2] = clock64();
     })
     // ---- status, in the reference's control-flow order (same as the oracle) ----

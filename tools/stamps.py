@@ -47,7 +47,8 @@ if "_diag" in os.path.basename(os.environ.get("ALACGPU_LIB", "")):
     lo = lambda x: (x & np.uint64(0xFFFFFFFF)).astype(np.float64)
     f16 = lambda x, sh: ((x >> np.uint64(sh)) & np.uint64(0xFFFF)).astype(np.float64)
     cols = {"plain_ok": hi(s[:, 1]), "fail_esc": lo(s[:, 1]), "z_units": hi(s[:, 4]), "esc_units": lo(s[:, 4]),
-            "fail_run": f16(s[:, 5], 48), "redo": f16(s[:, 5], 32), "full_units": f16(s[:, 6], 48), "late_run": f16(s[:, 6], 32)}
+            "fail_run": f16(s[:, 5], 48), "redo": f16(s[:, 5], 32), "full_units": f16(s[:, 6], 48), "late_run": f16(s[:, 6], 32),
+            "wide_units": hi(s[:, 7]), "fail_range": lo(s[:, 7])}
     order = np.argsort(dur)
     print("per-workgroup unit counts      mean   | fastest 3 workgroups           | slowest 5 workgroups")
     for k, v in cols.items():
