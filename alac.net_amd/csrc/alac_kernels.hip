@@ -106,7 +106,7 @@ struct TierState {
 };
 
 // After a tier-1-like pass: the parked lanes (see spec_unit) drop out of the verdict and get their state back.
-template <bool WANT_R, int QSTRIDE>
+template <bool WANT_R, int QSTRIDE, int CNT = SPEC_UNIT>
 __device__ __forceinline__ void spec_unpark(Rice& rs, const Rice& snap, bool parked, uint32_t& xmax, int& hmin, int* q) {
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(parked) != 0, 0)) {
         xmax = parked ? 0u : xmax;
@@ -114,10 +114,10 @@ __device__ __forceinline__ void spec_unpark(Rice& rs, const Rice& snap, bool par
         if (parked) {
             rs.w0 = snap.w0; rs.w1 = snap.w1; rs.w2 = snap.w2;
             rs.cur = snap.cur; rs.ra = snap.ra; rs.hist = snap.hist;
-            rs.zrun = snap.zrun - SPEC_UNIT;
+            rs.zrun = snap.zrun - CNT;
             if (WANT_R) {
 #pragma unroll
-                for (int ii = 0; ii < SPEC_UNIT; ii++) q[ii * QSTRIDE] = 0;
+                for (int ii = 0; ii < CNT; ii++) q[ii * QSTRIDE] = 0;
             }
         }
     }
@@ -253,6 +253,43 @@ __device__ __forceinline__ bool spec_unit(Rice& rs, TierState& ts, const RiceCfg
         SPEC_COUNT(late_run);
         return false;
     }
+    return true;
+}
+
+// A whole chunk as ONE unit of the escape tier, for a wave that is on that tier to stay (loud passages: the slowest workgroups
+// of a small batch spend most of their units there; 24-bit streams without shift bytes are coded in escape codes throughout) --
+// the code between two units costs this wave a quarter of the steps themselves.  Taken when the hold has at least
+// ALAC_ESC_CHUNK units to go (0: never) and no stream is in a zero run that ends inside the chunk; a new run symbol (not seen
+// in a loud passage) restores the state and returns false: the chunk is then decoded unit by unit.  Raw values of up to 23
+// bits only (the same for wider ones -- the second launch's cfg3 -- measured level at the BASELINE sizes).
+// (Measured, profiles/experiments/r3_chunk_units.txt: cfg2 at 4096 packets 0.697 -> 0.676 ms; the slowest workgroup 1.66 M ->
+// 1.57 M cycles, an escape-tier unit 599 -> 280 cycles above a plain one.  The same for the PLAIN tier lost 1.5 .. 6 %.)
+#ifndef ALAC_ESC_CHUNK
+#define ALAC_ESC_CHUNK 0
+#endif
+template <int QSTRIDE, int CNT>
+__device__ __forceinline__ bool esc_chunk(Rice& rs, TierState& ts, const RiceCfg& c, uint32_t ring, int* q, SpecStats& st) {
+    const bool parked = rs.zrun >= CNT;
+    if (__builtin_amdgcn_ballot_w64(rs.nforce == 0u && !parked) != 0) return false;
+    if (__builtin_amdgcn_ballot_w64(c.rss > 23) != 0) return false;
+    const Rice snap = rs;
+    uint32_t xmax = 0;
+    int hmin = 0x7FFFFFFF;
+    int acc[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int ii = 0; ii < CNT; ii++) {
+        const int r = rice_spec_step_esc<true, true>(rs, c, ring, xmax, hmin);
+        spec_store<QSTRIDE>(q, ii, acc, r);
+    }
+    spec_unpark<true, QSTRIDE, CNT>(rs, snap, parked, xmax, hmin, q);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(hmin < 128) != 0, 0)) {
+        rs = snap;
+        return false;
+    }
+    const bool sawesc = __builtin_amdgcn_ballot_w64(xmax > 8u) != 0;
+    ts.full_left = sawesc ? ts.hold : max(ts.full_left - CNT / SPEC_UNIT, 0);
+    ts.since = sawesc ? 0 : ts.since + CNT / SPEC_UNIT;
+    DIAG_ONLY(st.esc_units += CNT / SPEC_UNIT;)
     return true;
 }
 
@@ -441,14 +478,19 @@ __device__ __forceinline__ uint32_t ab_entropy_pass(const alac_decode_params& p,
             for (; c < cf_end; c++) {
                 const int i0 = c * AB_CHUNK;
                 int* q = qa + (c & 1) * qodd;
+                bool whole = false;     // the whole chunk as one unit of the escape tier (esc_chunk)
+                if (ALAC_ESC_CHUNK && ts.full_left >= ALAC_ESC_CHUNK)
+                    whole = esc_chunk<QS1, AB_CHUNK>(rs, ts, kc, kring, q, st);
+                if (!whole) {
 #pragma unroll
-                for (int u = 0; u < AB_CHUNK; u += SPEC_UNIT) {
-                    const bool redo = !spec_unit<true, QS1, true>(rs, ts, kc, kring, q + u * QS1, st);
-                    if (__builtin_expect(redo, 0)) {
-                        SPEC_COUNT(redo);
-                        for (int ii = 0; ii < SPEC_UNIT; ii++) {
-                            const int r = rice_step(rs, kc, kn - 1 - (i0 + u + ii), i0 + u + ii, &flags, kring);
-                            q[(u + ii) * QS1] = ab_zigzag(r);
+                    for (int u = 0; u < AB_CHUNK; u += SPEC_UNIT) {
+                        const bool redo = !spec_unit<true, QS1, true>(rs, ts, kc, kring, q + u * QS1, st);
+                        if (__builtin_expect(redo, 0)) {
+                            SPEC_COUNT(redo);
+                            for (int ii = 0; ii < SPEC_UNIT; ii++) {
+                                const int r = rice_step(rs, kc, kn - 1 - (i0 + u + ii), i0 + u + ii, &flags, kring);
+                                q[(u + ii) * QS1] = ab_zigzag(r);
+                            }
                         }
                     }
                 }
