@@ -63,3 +63,29 @@ def test_full_size_configs_equal_the_oracle(cfg):
     r, j = _run(["--config", str(cfg), "--steps", "2", "--warmup", "1", "--cpu-seconds", "0.2", "--no-host-path"])
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert j["parity_vs_oracle"] is True and j["status_ok"] is True
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,per_gpu", [(4, 8192), (5, 4096)])
+def test_every_rank_shard_of_the_eight_gpu_configs_equals_the_oracle(cfg, per_gpu, oracle, synth):
+    """BASELINE configs 4 and 5 are whole-job batches of 65 536 / 32 768 packets over 8 GPUs.  bench.py gives rank r the
+    packets [r * per_gpu, (r + 1) * per_gpu) of the job (make_config_batch(first_index=...)); rank 0's shard is compared with
+    the oracle by test_full_size_configs_equal_the_oracle.  Here the shards of ranks 1..7 go through the same C-ABI entry, one
+    after the other on the one GPU there is, every sample against the oracle: the whole job has then been decoded bit-exactly at
+    its full size, rank by rank."""
+    import numpy as np
+    import alac.net_amd as pkg
+
+    for rank in range(1, 8):
+        b = synth.make_config_batch(cfg, n_packets=per_gpu, first_index=rank * per_gpu)
+        with pkg.AlacGpuContext(b["stream_cfgs"], device=0) as ctx:
+            gp, gob, gos, gst = ctx.decode_batch(b["blob"], b["offsets"], b["sizes"], b["cfg_idx"], b["slot_ints"])
+        op, oob, oos, ost = oracle.decode_batch(oracle.make_cfgs(b["stream_cfgs"]), b["blob"], b["offsets"], b["sizes"],
+                                                 b["cfg_idx"], b["slot_ints"], n_threads=16)
+        assert np.array_equal(gst, ost) and np.array_equal(gob, oob) and np.array_equal(gos, oos), rank
+        ci = np.zeros(per_gpu, dtype=int) if b["cfg_idx"] is None else b["cfg_idx"].astype(int)
+        nc = np.array([b["stream_cfgs"][int(i)][5] for i in ci], dtype=np.int64)
+        cnt = np.where(ost == 0, oos.astype(np.int64) * nc, 0)
+        mask = np.arange(gp.shape[1])[None, :] < cnt[:, None]
+        assert np.array_equal(gp[mask], op[mask]), rank
+        assert (ost == 0).mean() > 0.9
