@@ -86,6 +86,11 @@ constexpr int ESC_HOLD = ALAC_ESC_HOLD;
 #ifndef ALAC_ESC_LONG
 #define ALAC_ESC_LONG 1
 #endif
+// What keeps the hold of the narrow escape tier alive: a unary prefix above this in the unit (8: an escape code, nothing less;
+// the small-batch build: 7 -- a prefix of eight ones says that the next escape code is close: -0.5 .. -1 %, r3_chunk_units.txt 8)
+#ifndef ALAC_ESC_PREFIX
+#define ALAC_ESC_PREFIX 8
+#endif
 // Streams beyond the narrow plain step's arithmetic (rice_spec_step: full-scale noise) stay on the wide plain step for WIDE_HOLD
 // units at a time.
 #ifndef ALAC_WIDE_HOLD
@@ -219,7 +224,7 @@ __device__ __forceinline__ bool spec_unit(Rice& rs, TierState& ts, const RiceCfg
             if (WANT_R) spec_store<QSTRIDE>(q, ii, acc, r);
         }
         spec_unpark<WANT_R, QSTRIDE>(rs, snap, parked, xmax, hmin, q);
-        const bool sawesc = __builtin_amdgcn_ballot_w64(xmax > 8u) != 0;
+        const bool sawesc = __builtin_amdgcn_ballot_w64(xmax > (unsigned)ALAC_ESC_PREFIX) != 0;
         ts.full_left = sawesc ? ts.hold : ts.full_left - 1;
         ts.since = sawesc ? 0 : ts.since + 1;
         SPEC_COUNT(esc_units);
@@ -286,7 +291,7 @@ __device__ __forceinline__ bool esc_chunk(Rice& rs, TierState& ts, const RiceCfg
         rs = snap;
         return false;
     }
-    const bool sawesc = __builtin_amdgcn_ballot_w64(xmax > 8u) != 0;
+    const bool sawesc = __builtin_amdgcn_ballot_w64(xmax > (unsigned)ALAC_ESC_PREFIX) != 0;
     ts.full_left = sawesc ? ts.hold : max(ts.full_left - CNT / SPEC_UNIT, 0);
     ts.since = sawesc ? 0 : ts.since + CNT / SPEC_UNIT;
     DIAG_ONLY(st.esc_units += CNT / SPEC_UNIT;)
